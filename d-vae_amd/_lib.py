@@ -1,0 +1,119 @@
+"""ctypes binding of libdvae_hip.so (C ABI in include/dvae_hip.h).
+
+The library is built in-tree by ``make -C d-vae_amd/csrc`` (see
+``__graft_entry__.build``).  There is no fallback: if the shared object is
+missing every entry point raises, it never routes to a CPU path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvae_hip.so")
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
+c_ll = ctypes.c_longlong
+
+
+class DvaeDims(ctypes.Structure):
+    """Mirror of ``struct dvae_dims``."""
+    _fields_ = [(n, c_int) for n in (
+        "B", "N", "C", "H", "Z", "mod", "bidir", "npos",
+        "HP", "ZP", "EH", "EHP", "VHP", "CP")]
+
+
+class PackEntry(ctypes.Structure):
+    """Mirror of ``struct dvae_pack_entry``."""
+    _fields_ = [("raw", ctypes.c_uint64), ("grad", ctypes.c_int64),
+                ("aux_raw", ctypes.c_uint64), ("aux_grad", ctypes.c_int64),
+                ("dst_off", ctypes.c_int64),
+                ("rows", c_int), ("cols", c_int), ("raw_ld", c_int), ("raw_col0", c_int),
+                ("dst_ld", c_int), ("kind", c_int)]
+
+
+class DvaeError(RuntimeError):
+    pass
+
+
+class GraphError(AssertionError):
+    """Adjacency is not a 0/1 strictly lower-triangular DAG.  The reference
+    reports shape/contract violations with ``assert`` (dvae_model.py:62,84,192)."""
+
+
+# name -> (restype, argtypes); every symbol declared in include/dvae_hip.h
+_P = ctypes.POINTER
+SIGNATURES = {
+    "dvae_last_error": (ctypes.c_char_p, []),
+    "dvae_abi_version": (c_int, []),
+    "dvae_dims_init": (c_int, [_P(DvaeDims)]),
+    "dvae_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                              c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dvae_sched_bytes": (c_size_t, [c_int, c_int]),
+    "dvae_sched_build": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dvae_sched_export": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dvae_enc_param_floats": (c_size_t, [_P(DvaeDims)]),
+    "dvae_dec_param_floats": (c_size_t, [_P(DvaeDims)]),
+    "dvae_enc_param_count": (c_int, [_P(DvaeDims)]),
+    "dvae_dec_param_count": (c_int, [_P(DvaeDims)]),
+    "dvae_enc_pack_table": (c_int, [_P(DvaeDims), c_void_p, c_void_p, c_void_p, c_int]),
+    "dvae_dec_pack_table": (c_int, [_P(DvaeDims), c_void_p, c_void_p, c_void_p, c_int]),
+    "dvae_pack_params": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "dvae_unpack_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dvae_enc_ws_bytes": (c_size_t, [_P(DvaeDims), c_int, c_int]),
+    "dvae_encoder_fwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 12),
+    "dvae_encoder_bwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 11),
+    "dvae_dec_ws_bytes": (c_size_t, [_P(DvaeDims), c_int, c_int]),
+    "dvae_decoder_fwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 11),
+    "dvae_decoder_bwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 12),
+    "dvae_reparam_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    "dvae_reparam_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    "dvae_elbo_ws_bytes": (c_size_t, [c_int]),
+    "dvae_elbo": (c_int, [_P(DvaeDims)] + [c_void_p] * 7 + [c_float] + [c_void_p] * 7),
+    "dvae_predict_ws_bytes": (c_size_t, [_P(DvaeDims)]),
+    "dvae_decoder_predict": (c_int, [_P(DvaeDims)] + [c_void_p] * 9),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises DvaeError if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DvaeError(
+            "libdvae_hip.so not found at %s: build it with `make -C d-vae_amd/csrc` "
+            "(there is no CPU fallback for the D-VAE hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status == 0:
+        return
+    msg = load().dvae_last_error().decode("utf-8", "replace")
+    if status == -3:
+        raise GraphError(msg)
+    raise DvaeError("libdvae_hip status %d: %s" % (status, msg))
+
+
+def make_dims(B, N, C, H, Z, mod, bidir, npos):
+    d = DvaeDims()
+    d.B, d.N, d.C, d.H, d.Z = int(B), int(N), int(C), int(H), int(Z)
+    d.mod = {None: 0, "bn": 1}[mod]
+    d.bidir = int(bool(bidir))
+    d.npos = int(npos) if mod is None else 0
+    check(load().dvae_dims_init(ctypes.byref(d)))
+    return d
+
+
+def sched_info_ints(N):
+    return 8 + 3 * (N + 1)

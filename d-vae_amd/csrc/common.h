@@ -1,0 +1,61 @@
+// Shared declarations for the D-VAE gfx950 library (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dvae_hip.h"
+
+#define DVAE_MAX_N 128      // max nodes per graph (adjacency rows kept as 128-bit masks)
+#define DVAE_MAX_C 32       // max node types
+#define DVAE_BITW 4         // 32-bit words per adjacency bit-row
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// last error text (thread-local), read through dvae_last_error()
+void dvae_set_error(const char* fmt, ...);
+
+#define DVAE_CHECK_HIP(expr)                                                          \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      dvae_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                       \
+      return DVAE_ERR_HIP;                                                            \
+    }                                                                                 \
+  } while (0)
+
+#define DVAE_REQUIRE(cond, ...)      \
+  do {                               \
+    if (!(cond)) {                   \
+      dvae_set_error(__VA_ARGS__);   \
+      return DVAE_ERR_ARG;           \
+    }                                \
+  } while (0)
+
+#define DVAE_TRY(expr)              \
+  do {                              \
+    int s_ = (expr);                \
+    if (s_ != DVAE_OK) return s_;   \
+  } while (0)
+
+#define DVAE_LAUNCH_CHECK() DVAE_CHECK_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------
+// internal launchers shared between translation units
+// ---------------------------------------------------------------------------
+struct GemmDesc {
+  const float* A; int lda; int a_kmajor;   // a_kmajor=0: A[M][K]; 1: A[K][M]
+  const float* B; int ldb; int b_kmajor;   // b_kmajor=0: B[N][K]; 1: B[K][N]
+  float* C; int ldc;
+  int M, N, K;
+  const float* bias;   // per column n, or null
+  int relu;            // apply max(0,.) after bias
+  int accumulate;      // C += result
+};
+// C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
+int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);

@@ -1,0 +1,486 @@
+// Host orchestration of the level-synchronous encoder / teacher-forced decoder
+// (forward and backward).  Everything here is launches on the caller's stream;
+// no allocation, no synchronisation.
+#include <algorithm>
+
+#include "layout.h"
+
+namespace {
+
+struct Carver {
+  char* base; size_t off;
+  float* f(size_t n) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off = (off + n * sizeof(float) + 255) & ~(size_t)255;
+    return p;
+  }
+};
+
+constexpr size_t GEMM_WS_BYTES = (size_t)96 << 20;
+
+size_t part_floats_for(const dvae_dims& d) {
+  size_t m = (size_t)(d.C + 2) * 3 * d.HP * 512;
+  m = std::max(m, (size_t)std::max(d.npos, 1) * 2 * d.HP * 128);
+  m = std::max(m, (size_t)(d.EHP + 4) * 2048);
+  m = std::max(m, (size_t)d.EHP * 512);
+  return m;
+}
+
+void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP) {
+  s.prefix = prefix;
+  s.RH = prefix ? R + E : R;
+  const size_t rh = (size_t)std::max(s.RH, 1), r = (size_t)std::max(R, 1);
+  s.AGG = c.f(rh * HP);
+  s.GH = c.f(rh * 3 * HP);
+  s.GHN = c.f(rh * HP);
+  s.DH = c.f(rh * HP);
+  s.GMP = c.f(r * 2 * HP);
+  s.GM = c.f(r * HP);
+  if (prefix) {
+    s.HV = c.f(rh * HP);
+    s.Hn = c.f(r * HP);
+    s.DHn = c.f(r * HP);
+  } else {
+    s.Hn = c.f(r * HP);
+    s.HV = s.Hn;
+    s.DHn = nullptr;
+  }
+}
+
+struct EncWs {
+  SweepBufs f, r;
+  float *HVF, *ML, *DML, *DHVF;
+  float *HVC, *CAT, *DHVC, *DCAT;   // bidirectional chain
+  float* gemm_ws; float* part; size_t part_floats;
+  size_t bytes;
+};
+
+EncWs enc_ws(const dvae_dims& d, int R, int E, void* base) {
+  EncWs w;
+  Carver c{(char*)base, 0};
+  carve_sweep(c, w.f, 0, R, E, d.HP);
+  const size_t B = d.B;
+  w.ML = c.f(B * 2 * d.ZP);
+  w.DML = c.f(B * 2 * d.ZP);
+  w.DHVF = c.f(B * d.HP);
+  if (d.bidir) {
+    carve_sweep(c, w.r, 0, R, E, d.HP);
+    w.HVC = c.f((size_t)(d.N + 1) * B * d.HP);
+    w.CAT = c.f((size_t)d.N * B * 2 * d.HP);
+    w.DHVC = c.f((size_t)(d.N + 1) * B * d.HP);
+    w.DCAT = c.f(B * 2 * d.HP);
+    w.HVF = w.HVC + (size_t)d.N * B * d.HP;
+  } else {
+    w.r = SweepBufs{};
+    w.HVC = w.CAT = w.DHVC = w.DCAT = nullptr;
+    w.HVF = c.f(B * d.HP);
+  }
+  w.gemm_ws = c.f(GEMM_WS_BYTES / 4);
+  w.part_floats = part_floats_for(d);
+  w.part = c.f(w.part_floats);
+  w.bytes = c.off;
+  return w;
+}
+
+struct DecWs {
+  SweepBufs s;
+  float *ZPAD, *H0, *DH0, *DZP;
+  float *A, *DA, *Bq, *DBq, *Cq, *DCq;
+  float *GS, *DGS, *VH, *DVH, *TL, *DTL;
+  float* gemm_ws; float* part; size_t part_floats;
+  size_t bytes;
+};
+
+DecWs dec_ws(const dvae_dims& d, int R, int E, void* base) {
+  DecWs w;
+  Carver c{(char*)base, 0};
+  carve_sweep(c, w.s, 1, R, E, d.HP);
+  const size_t B = d.B, r = std::max(R, 1), rh = std::max(R + E, 1);
+  w.ZPAD = c.f(B * d.ZP);
+  w.H0 = c.f(B * d.HP);
+  w.DH0 = c.f(B * d.HP);
+  w.DZP = c.f(B * d.ZP);
+  w.A = c.f(rh * d.EHP);
+  w.DA = c.f(rh * d.EHP);
+  w.Bq = c.f(r * d.EHP);
+  w.DBq = c.f(r * d.EHP);
+  w.Cq = d.mod ? c.f(B * d.EHP) : nullptr;
+  w.DCq = d.mod ? c.f(B * d.EHP) : nullptr;
+  w.GS = c.f(r * d.HP);
+  w.DGS = c.f(r * d.HP);
+  w.VH = c.f(r * d.VHP);
+  w.DVH = c.f(r * d.VHP);
+  w.TL = c.f(r * d.CP);
+  w.DTL = c.f(r * d.CP);
+  w.gemm_ws = c.f(GEMM_WS_BYTES / 4);
+  w.part_floats = part_floats_for(d);
+  w.part = c.f(w.part_floats);
+  w.bytes = c.off;
+  return w;
+}
+
+// ---- GEMM shorthands ---------------------------------------------------------
+struct G {
+  float* ws; hipStream_t st;
+  // Y[M][N] (+)= X[M][K] W[N][K]^T + bias
+  int nt(const float* X, int ldx, const float* W, int ldw, float* Y, int ldy, int M, int N, int K,
+         const float* bias = nullptr, int relu = 0, int acc = 0) const {
+    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc};
+    return gemm_f32(d, ws, GEMM_WS_BYTES, st);
+  }
+  // dX[M][N] (+)= dY[M][K] W[K][N]
+  int nn(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K,
+         int acc = 0) const {
+    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc};
+    return gemm_f32(d, ws, GEMM_WS_BYTES, st);
+  }
+  // dW[M][N] = dY[K][M]^T X[K][N]   (K = rows)
+  int tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, int K) const {
+    if (K <= 0) {
+      if (hipMemset2DAsync(dW, (size_t)ldw * 4, 0, (size_t)N * 4, M, st) != hipSuccess) {
+        dvae_set_error("memset2d failed");
+        return DVAE_ERR_HIP;
+      }
+      return DVAE_OK;
+    }
+    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, 0};
+    return gemm_f32(d, ws, GEMM_WS_BYTES, st);
+  }
+};
+
+struct Levels {
+  int R, E, nlev;
+  const int* ls;   // node-row level starts [nlev+1]
+  const int* es;   // edge-space level starts (forward only)
+};
+
+Levels levels_of(const dvae_dims& d, const int* info, int dir) {
+  Levels l;
+  l.R = info[1]; l.E = info[2]; l.nlev = info[3 + dir];
+  l.ls = info + 8 + dir * (d.N + 1);
+  l.es = info + 8 + 2 * (d.N + 1);
+  return l;
+}
+
+int check_info(const dvae_dims& d, const int* info) {
+  DVAE_REQUIRE(info, "null schedule info");
+  if (info[0] != 0) {
+    dvae_set_error("adjacency must be 0/1 and strictly lower-triangular within each graph's size");
+    return DVAE_ERR_GRAPH;
+  }
+  DVAE_REQUIRE(info[1] >= 0 && info[1] <= d.B * d.N, "schedule info is stale or corrupt");
+  return DVAE_OK;
+}
+
+struct SweepW {
+  GruW gru; const float* gm;   // gm: Wgm|posb (None) or WgmT|bgm (bn)
+};
+
+// level sweep forward (dvae_model.py:63-87 / :93-116 / the final-state part of :196-249)
+int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
+              const float* x, const float* h0, const G& g) {
+  const int HP = d.HP;
+  hipStream_t st = g.st;
+  if (lv.R <= 0) return DVAE_OK;
+  if (d.mod == 1) {
+    DVAE_TRY(k_gm_bn_fwd(S, lv.R, b, x, d.N, d.C, w.gm, w.gm + (size_t)d.C * 2 * HP, HP, st));
+    DVAE_TRY(k_agg_fwd(S, 0, lv.R, b, h0, HP, st));
+    DVAE_TRY(g.nt(b.AGG, HP, w.gru.Whh, HP, b.GH, 3 * HP, b.RH, 3 * HP, HP));
+    DVAE_TRY(k_gru_fwd(S, 0, b.RH, b, x, d.N, d.C, w.gru, HP, st));
+    return DVAE_OK;
+  }
+  for (int L = 0; L < lv.nlev; ++L) {
+    const int ns = lv.ls[L], ne = lv.ls[L + 1];
+    const int p0 = b.prefix ? ns + lv.es[L] : ns, p1 = b.prefix ? ne + lv.es[L + 1] : ne;
+    DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st));
+    if (L == 0 && !h0) {
+      // no predecessors and no seed: h_in = 0, the hidden GEMM vanishes
+      DVAE_CHECK_HIP(hipMemsetAsync(b.GH + (size_t)p0 * 3 * HP, 0, (size_t)(p1 - p0) * 3 * HP * 4, st));
+    } else {
+      DVAE_TRY(g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0,
+                    3 * HP, HP));
+    }
+    DVAE_TRY(k_gru_fwd(S, p0, p1, b, x, d.N, d.C, w.gru, HP, st));
+    if (L + 1 < lv.nlev) {   // nodes of the last level have no successors
+      DVAE_TRY(g.nt(b.Hn + (size_t)ns * HP, HP, w.gm, HP, b.GMP + (size_t)ns * 2 * HP, 2 * HP, ne - ns, 2 * HP,
+                    HP));
+      DVAE_TRY(k_gm_fwd(S, ns, ne, b, w.gm + (size_t)2 * HP * HP, HP, st));
+    }
+  }
+  return DVAE_OK;
+}
+
+// reverse-level sweep: DH holds dL/dHV on entry, dL/dAGG on exit
+int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
+              bool seeded, const G& g) {
+  const int HP = d.HP;
+  hipStream_t st = g.st;
+  if (lv.R <= 0) return DVAE_OK;
+  if (d.mod == 1) {
+    DVAE_TRY(k_gru_bwd(S, 0, b.RH, b, HP, st));
+    DVAE_TRY(g.nn(b.GH, 3 * HP, w.gru.Whh, HP, b.DH, HP, b.RH, HP, 3 * HP, 1));
+    DVAE_TRY(k_dgm_bwd(S, 0, lv.R, b, HP, st));
+    return DVAE_OK;
+  }
+  float* dtarget = b.prefix ? b.DHn : b.DH;
+  for (int L = lv.nlev - 1; L >= 0; --L) {
+    const int ns = lv.ls[L], ne = lv.ls[L + 1];
+    const int p0 = b.prefix ? ns + lv.es[L] : ns, p1 = b.prefix ? ne + lv.es[L + 1] : ne;
+    if (L + 1 < lv.nlev) {
+      DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
+      DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
+                    2 * HP, 1));
+    }
+    DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
+    if (L > 0 || seeded)
+      DVAE_TRY(g.nn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DH + (size_t)p0 * HP, HP, p1 - p0, HP,
+                    3 * HP, 1));
+  }
+  return DVAE_OK;
+}
+
+// weight gradients of one sweep, reduced over all rows after the sweep
+int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
+                float* Ggru, float* Ggm, float* part, size_t part_floats, const G& g) {
+  const int HP = d.HP;
+  hipStream_t st = g.st;
+  // dWhh = dgh^T . h_in
+  DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, lv.R > 0 ? b.RH : 0));
+  if (lv.R > 0) {
+    DVAE_TRY(k_gru_wgrad(S, b, x, d.N, d.C, HP, Ggru + (size_t)3 * HP * HP, part, part_floats, st));
+  } else {
+    DVAE_CHECK_HIP(hipMemsetAsync(Ggru + (size_t)3 * HP * HP, 0, (size_t)(d.C + 2) * 3 * HP * 4, st));
+  }
+  if (d.mod == 0) {
+    const int Rg = lv.nlev > 0 ? lv.ls[lv.nlev - 1] : 0;   // nodes that have a gate/map output
+    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
+    if (Rg > 0) {
+      DVAE_TRY(k_gm_wgrad_pos(S, Rg, b, d.npos, HP, Ggm + (size_t)2 * HP * HP, part, part_floats, st));
+    } else {
+      DVAE_CHECK_HIP(hipMemsetAsync(Ggm + (size_t)2 * HP * HP, 0, (size_t)d.npos * 2 * HP * 4, st));
+    }
+  } else {
+    if (lv.R > 0) {
+      DVAE_TRY(k_gm_wgrad_bn(S, lv.R, b, x, d.N, d.C, HP, Ggm, part, part_floats, st));
+    } else {
+      DVAE_CHECK_HIP(hipMemsetAsync(Ggm, 0, (size_t)(d.C + 1) * 2 * HP * 4, st));
+    }
+  }
+  return DVAE_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// encoder
+// ===========================================================================
+extern "C" size_t dvae_enc_ws_bytes(const dvae_dims* d, int R, int E) { return enc_ws(*d, R, E, nullptr).bytes; }
+
+extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* sizes, const void* sched,
+                                const int* info, const float* P, void* ws, float* hv, float* mu,
+                                float* logvar, float* states, float* states_rev, void* stream) {
+  DVAE_REQUIRE(dp && x && sched && P && ws, "encoder_fwd: null pointer");
+  const dvae_dims& d = *dp;
+  DVAE_TRY(check_info(d, info));
+  hipStream_t st = (hipStream_t)stream;
+  const SchedView sv = sched_view(const_cast<void*>(sched), d.B, d.N);
+  const Levels lf = levels_of(d, info, 0);
+  EncWs w = enc_ws(d, lf.R, lf.E, ws);
+  const EncLayout L = enc_layout(d);
+  const G g{w.gemm_ws, st};
+  const int HP = d.HP, B = d.B;
+
+  SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
+  DVAE_TRY(sweep_fwd(d, sv.dir[0], lf, w.f, wf, x, nullptr, g));
+  if (d.bidir) {
+    const Levels lr = levels_of(d, info, 1);
+    SweepW wr{gru_at(P + L.gru_b, HP, d.C), P + L.gm_b};
+    DVAE_TRY(sweep_fwd(d, sv.dir[1], lr, w.r, wr, x, nullptr, g));
+    // lin01 chain, applied once per reverse-sweep step (dvae_model.py:119)
+    DVAE_TRY(k_take_last_fwd(sv.dir[0], sizes, B, d.N, w.f.Hn, w.HVC, HP, st));
+    for (int t = 0; t < d.N; ++t) {
+      float* hv_t = w.HVC + (size_t)t * B * HP;
+      float* cat = w.CAT + (size_t)t * B * 2 * HP;
+      DVAE_TRY(k_chain_cat(sv.dir[1], sizes, B, d.N, t, hv_t, w.r.Hn, cat, HP, st));
+      DVAE_TRY(g.nt(cat, 2 * HP, P + L.W01, 2 * HP, hv_t + (size_t)B * HP, HP, B, HP, 2 * HP, P + L.b01));
+      DVAE_TRY(k_chain_select(sizes, B, t, hv_t, hv_t + (size_t)B * HP, HP, st));
+    }
+  } else {
+    DVAE_TRY(k_take_last_fwd(sv.dir[0], sizes, B, d.N, w.f.Hn, w.HVF, HP, st));
+  }
+  // mu | logvar heads (dvae_model.py:121-122)
+  DVAE_TRY(g.nt(w.HVF, HP, P + L.Wml, HP, w.ML, 2 * d.ZP, B, 2 * d.ZP, HP, P + L.bml));
+  if (hv) DVAE_TRY(k_unpad_rows(w.HVF, HP, B, d.H, hv, st));
+  if (mu) DVAE_TRY(k_unpad_rows(w.ML, 2 * d.ZP, B, d.Z, mu, st));
+  if (logvar) DVAE_TRY(k_unpad_rows(w.ML + d.ZP, 2 * d.ZP, B, d.Z, logvar, st));
+  if (states) {
+    DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
+    DVAE_TRY(k_rows_to_dense(sv.dir[0], lf.R, w.f.Hn, HP, states, d.N, d.H, st));
+  }
+  if (states_rev && d.bidir) {
+    DVAE_CHECK_HIP(hipMemsetAsync(states_rev, 0, (size_t)B * d.N * d.H * 4, st));
+    DVAE_TRY(k_rows_to_dense(sv.dir[1], lf.R, w.r.Hn, HP, states_rev, d.N, d.H, st));
+  }
+  return DVAE_OK;
+}
+
+extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* sizes, const void* sched,
+                                const int* info, const float* P, void* ws, const float* d_hv,
+                                const float* d_mu, const float* d_logvar, float* Gp, void* stream) {
+  DVAE_REQUIRE(dp && x && sched && P && ws && Gp, "encoder_bwd: null pointer");
+  const dvae_dims& d = *dp;
+  DVAE_TRY(check_info(d, info));
+  hipStream_t st = (hipStream_t)stream;
+  const SchedView sv = sched_view(const_cast<void*>(sched), d.B, d.N);
+  const Levels lf = levels_of(d, info, 0);
+  EncWs w = enc_ws(d, lf.R, lf.E, ws);
+  const EncLayout L = enc_layout(d);
+  const G g{w.gemm_ws, st};
+  const int HP = d.HP, B = d.B, ZP = d.ZP;
+
+  // heads
+  DVAE_TRY(k_pad_rows(d_mu, B, d.Z, w.DML, 2 * ZP, ZP, st));
+  DVAE_TRY(k_pad_rows(d_logvar, B, d.Z, w.DML + ZP, 2 * ZP, ZP, st));
+  DVAE_TRY(g.nn(w.DML, 2 * ZP, P + L.Wml, HP, w.DHVF, HP, B, HP, 2 * ZP));
+  if (d_hv) DVAE_TRY(k_add_rows(w.DHVF, HP, d_hv, d.H, B, d.H, st));
+  DVAE_TRY(g.tn(w.DML, 2 * ZP, w.HVF, HP, Gp + L.Wml, HP, 2 * ZP, HP, B));
+  DVAE_TRY(k_colsum(w.DML, 2 * ZP, B, 2 * ZP, Gp + L.bml, w.part, w.part_floats, st));
+
+  DVAE_CHECK_HIP(hipMemsetAsync(w.f.DH, 0, (size_t)std::max(lf.R, 1) * HP * 4, st));
+  SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
+  if (d.bidir) {
+    const Levels lr = levels_of(d, info, 1);
+    SweepW wr{gru_at(P + L.gru_b, HP, d.C), P + L.gm_b};
+    DVAE_CHECK_HIP(hipMemsetAsync(w.r.DH, 0, (size_t)std::max(lf.R, 1) * HP * 4, st));
+    // chain backward; DHVC[t] = dL/d hv_t, DHVC[N] seeded by the heads
+    DVAE_CHECK_HIP(hipMemcpyAsync(w.DHVC + (size_t)d.N * B * HP, w.DHVF, (size_t)B * HP * 4,
+                                  hipMemcpyDeviceToDevice, st));
+    for (int t = d.N - 1; t >= 0; --t) {
+      float* d_t = w.DHVC + (size_t)t * B * HP;
+      float* d_next = d_t + (size_t)B * HP;
+      if (sizes) {
+        DVAE_CHECK_HIP(hipMemsetAsync(d_t, 0, (size_t)B * HP * 4, st));
+        DVAE_TRY(k_chain_mask(sizes, B, t, d_next, d_t, HP, st));
+      }
+      DVAE_TRY(g.nn(d_next, HP, P + L.W01, 2 * HP, w.DCAT, 2 * HP, B, 2 * HP, HP));
+      DVAE_TRY(k_chain_scatter(sv.dir[1], sizes, B, d.N, t, w.DCAT, d_t, w.r.DH, HP, st));
+    }
+    DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVC, w.f.DH, HP, st));
+    // dW01 over all N*B chain rows, db01
+    DVAE_TRY(g.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
+    DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, w.part, w.part_floats, st));
+    DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g));
+    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, w.part, w.part_floats, g));
+  } else {
+    DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
+  }
+  DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g));
+  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, w.part, w.part_floats, g));
+  return DVAE_OK;
+}
+
+// ===========================================================================
+// teacher-forced decoder
+// ===========================================================================
+extern "C" size_t dvae_dec_ws_bytes(const dvae_dims* d, int R, int E) { return dec_ws(*d, R, E, nullptr).bytes; }
+
+extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float* x, const int* sizes,
+                                const void* sched, const int* info, const float* P, void* ws,
+                                float* edge_logits, float* type_logits, float* states, void* stream) {
+  (void)sizes;
+  DVAE_REQUIRE(dp && z && x && sched && P && ws && edge_logits && type_logits, "decoder_fwd: null pointer");
+  const dvae_dims& d = *dp;
+  DVAE_TRY(check_info(d, info));
+  hipStream_t st = (hipStream_t)stream;
+  const SchedView sv = sched_view(const_cast<void*>(sched), d.B, d.N);
+  const SchedDir& S = sv.dir[0];
+  const Levels lv = levels_of(d, info, 0);
+  DecWs w = dec_ws(d, lv.R, lv.E, ws);
+  const DecLayout L = dec_layout(d);
+  const G g{w.gemm_ws, st};
+  const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E;
+
+  // h0 = lin1(z) (dvae_model.py:194)
+  DVAE_TRY(k_pad_rows(z, B, d.Z, w.ZPAD, d.ZP, d.ZP, st));
+  DVAE_TRY(g.nt(w.ZPAD, d.ZP, P + L.Wl1, d.ZP, w.H0, HP, B, HP, d.ZP, P + L.bl1));
+  SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
+  DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g));
+
+  // add_edge: first layer split by input block (dvae_model.py:211-218)
+  DVAE_TRY(g.nt(w.s.HV, HP, P + L.W1a, HP, w.A, d.EHP, RH, d.EHP, HP));
+  DVAE_TRY(g.nt(w.s.Hn, HP, P + L.W1b, HP, w.Bq, d.EHP, R, d.EHP, HP, P + L.b1));
+  if (d.mod) DVAE_TRY(g.nt(w.H0, HP, P + L.W1c, HP, w.Cq, d.EHP, B, d.EHP, HP));
+  DVAE_CHECK_HIP(hipMemsetAsync(edge_logits, 0, (size_t)B * d.N * d.N * 4, st));
+  DVAE_TRY(k_pair_fwd(sv, R, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, d.EHP, st));
+
+  // add_vertex on the graph state seen before each node (dvae_model.py:199-200,251-257)
+  DVAE_TRY(k_graph_state_fwd(S, R, d.N, d.mod, w.s.Hn, w.H0, w.GS, HP, st));
+  DVAE_TRY(g.nt(w.GS, HP, P + L.Wv1, HP, w.VH, d.VHP, R, d.VHP, HP, P + L.bv1, 1));
+  DVAE_TRY(g.nt(w.VH, d.VHP, P + L.Wv2, d.VHP, w.TL, d.CP, R, d.CP, d.VHP, P + L.bv2));
+  DVAE_CHECK_HIP(hipMemsetAsync(type_logits, 0, (size_t)B * d.N * d.C * 4, st));
+  DVAE_TRY(k_rows_to_dense(S, R, w.TL, d.CP, type_logits, d.N, d.C, st));
+  if (states) {
+    DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
+    DVAE_TRY(k_rows_to_dense(S, R, w.s.Hn, HP, states, d.N, d.H, st));
+  }
+  return DVAE_OK;
+}
+
+extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float* x, const int* sizes,
+                                const void* sched, const int* info, const float* P, void* ws,
+                                const float* d_edge, const float* d_type, float* Gp, float* d_z,
+                                void* stream) {
+  (void)z;
+  DVAE_REQUIRE(dp && x && sched && P && ws && d_edge && d_type && Gp, "decoder_bwd: null pointer");
+  const dvae_dims& d = *dp;
+  DVAE_TRY(check_info(d, info));
+  hipStream_t st = (hipStream_t)stream;
+  const SchedView sv = sched_view(const_cast<void*>(sched), d.B, d.N);
+  const SchedDir& S = sv.dir[0];
+  const Levels lv = levels_of(d, info, 0);
+  DecWs w = dec_ws(d, lv.R, lv.E, ws);
+  const DecLayout L = dec_layout(d);
+  const G g{w.gemm_ws, st};
+  const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E, EHP = d.EHP;
+
+  // ---- add_edge ----
+  DVAE_TRY(k_pair_bwd_a(sv, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, w.part, w.part_floats, EHP, st));
+  DVAE_TRY(k_pair_bwd_b(sv, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
+  DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
+  DVAE_TRY(g.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
+  DVAE_TRY(g.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, R));
+  DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, w.part, w.part_floats, st));
+  if (d.mod) {
+    DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
+    DVAE_TRY(g.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
+  }
+  // ---- add_vertex ----
+  DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, st));
+  DVAE_TRY(g.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
+  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, st));
+  DVAE_TRY(g.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
+  DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, w.part, w.part_floats, st));
+  DVAE_TRY(g.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
+  DVAE_TRY(g.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
+  DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, w.part, w.part_floats, st));
+  DVAE_CHECK_HIP(hipMemsetAsync(w.DH0, 0, (size_t)B * HP * 4, st));
+  DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
+  // the W1b half of add_edge reads the final states
+  DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, R, HP, EHP, 1));
+
+  // ---- level sweep ----
+  SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
+  DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
+  DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
+  if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
+  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, w.part, w.part_floats, g));
+
+  // ---- lin1 ----
+  DVAE_TRY(g.tn(w.DH0, HP, w.ZPAD, d.ZP, Gp + L.Wl1, d.ZP, HP, d.ZP, B));
+  DVAE_TRY(k_colsum(w.DH0, HP, B, HP, Gp + L.bl1, w.part, w.part_floats, st));
+  if (d_z) {
+    DVAE_TRY(g.nn(w.DH0, HP, P + L.Wl1, d.ZP, w.DZP, d.ZP, B, d.ZP, HP));
+    DVAE_TRY(k_unpad_rows(w.DZP, d.ZP, B, d.Z, d_z, st));
+  }
+  return DVAE_OK;
+}

@@ -1,0 +1,303 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   C[M][N] (+)= sum_k A(m,k) * B(n,k)  (+ bias[n], relu)
+//
+// Every dense contraction of the D-VAE path goes through this one kernel
+// template: the GRU hidden GEMM, the gate/map GEMM, the add_vertex / add_edge
+// MLP halves, and all of their backward products.  The three shapes differ only
+// in which operand has its reduction dimension contiguous in memory:
+//   NT  (forward,  Y = X W^T)      A[M][K]  B[N][K]    a_kmajor=0 b_kmajor=0
+//   NN  (dX = dY W)                A[M][K]  B[K][N]    a_kmajor=0 b_kmajor=1
+//   TN  (dW = dY^T X, K = rows)    A[K][M]  B[K][N]    a_kmajor=1 b_kmajor=1
+// A "k-major" operand is staged into LDS exactly as it lies in memory ([k][m])
+// and read back with ds_read_b32 (32 consecutive floats per half-wave, no
+// conflicts); an "m-major" operand is staged as [m][k] with a 36-float row
+// stride and read with ds_read_b128, each half-wave taking 4 consecutive k.
+// The fp32 MFMA retires 32x32x2 in 64 cycles per SIMD, so LDS read width is
+// nowhere near the limit; what matters is that no transposed copy of any
+// weight or activation is ever written to HBM.
+//
+// The k order inside an 8-wide chunk is permuted (lane half h owns k = 4h..4h+3)
+// consistently for A and B, which only reorders the fp32 summation.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDM = BK + 4;  // row stride of an m-major LDS tile, floats
+
+template <int KM, int ROWS>
+struct Tile {
+  static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
+  static constexpr int LDS_FLOATS = KM ? BK * ROWS : ROWS * LDM;
+  float4 v[NV];
+
+  // rows: extent of the non-reduction dim; kend: end of this block's k range.
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int rows, int k0,
+                                       int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KM == 0) {
+        const int row = idx >> 3, kq = idx & 7;
+        const int r = r0 + row, k = k0 + kq * 4;
+        if (r < rows && k < kend) val = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k);
+      } else {
+        constexpr int RQ = ROWS / 4;
+        const int kr = idx / RQ, rq = idx % RQ;
+        const int k = k0 + kr, r = r0 + rq * 4;
+        if (k < kend && r < rows) val = *reinterpret_cast<const float4*>(P + (size_t)k * ld + r);
+      }
+      v[i] = val;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      if (KM == 0) {
+        const int row = idx >> 3, kq = idx & 7;
+        *reinterpret_cast<float4*>(lds + row * LDM + kq * 4) = v[i];
+      } else {
+        constexpr int RQ = ROWS / 4;
+        const int kr = idx / RQ, rq = idx % RQ;
+        *reinterpret_cast<float4*>(lds + kr * ROWS + rq * 4) = v[i];
+      }
+    }
+  }
+
+  // fragment for one 32-row sub-tile at rbase, k-chunk kc (8 wide): 4 values,
+  // value t belongs to k = kc*8 + 4*(lane>>5) + t.
+  static __device__ __forceinline__ float4 frag(const float* lds, int rbase, int kc, int lane) {
+    if (KM == 0) {
+      return *reinterpret_cast<const float4*>(lds + (rbase + (lane & 31)) * LDM + kc * 8 +
+                                              (lane >> 5) * 4);
+    } else {
+      const float* p = lds + (kc * 8 + (lane >> 5) * 4) * ROWS + rbase + (lane & 31);
+      return make_float4(p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]);
+    }
+  }
+};
+
+struct GemmParams {
+  const float* A; const float* B; float* C; const float* bias;
+  int lda, ldb, ldc;
+  int M, N, K;
+  int relu, accumulate;
+  int k_chunk;            // k range per blockIdx.y
+  long long c_split;      // C offset (floats) per blockIdx.y
+  int tiles_n, nblk;
+};
+
+// bijective XCD-aware remap: blocks that share blockIdx%8 (one XCD under
+// round-robin placement) get a contiguous run of tiles, so an XCD's L2 keeps
+// its own A panels.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int x = bid & 7, j = bid >> 3;
+  const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + j;
+}
+
+template <int AKM, int BKM, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  using TA = Tile<AKM, BM>;
+  using TB = Tile<BKM, BN>;
+  __shared__ __attribute__((aligned(16))) float lds[TA::LDS_FLOATS + TB::LDS_FLOATS];
+  float* As = lds;
+  float* Bs = lds + TA::LDS_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tile = xcd_remap(blockIdx.x, p.nblk);
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BN;
+  const int kb = blockIdx.y * p.k_chunk;
+  const int ke = min(p.K, kb + p.k_chunk);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  TA ta;
+  TB tb;
+  ta.load(p.A, p.lda, m0, p.M, kb, ke, tid);
+  tb.load(p.B, p.ldb, n0, p.N, kb, ke, tid);
+  ta.store(As, tid);
+  tb.store(Bs, tid);
+  __syncthreads();
+
+  for (int k0 = kb; k0 < ke; k0 += BK) {
+    const bool more = (k0 + BK) < ke;
+    if (more) {
+      ta.load(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
+      tb.load(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
+    }
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = TA::frag(As, wm * (BM / WM) + i * 32, kc, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = TB::frag(Bs, wn * (BN / WN) + j * 32, kc, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (more) {
+      ta.store(As, tid);
+      tb.store(Bs, tid);
+      __syncthreads();
+    }
+  }
+
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane&31,
+  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  float* C = p.C + (size_t)blockIdx.y * p.c_split;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.M) {
+          float v = acc[i][j][r] + bv;
+          float* dst = C + (size_t)row * p.ldc + col;
+          if (p.accumulate) v += *dst;
+          if (p.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+}
+
+// out[m][n] (+)= sum_s slab[s][m][n] + bias[n]
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, long long stride,
+                                     float* __restrict__ C, int ldc, int M, int N,
+                                     const float* __restrict__ bias, int relu, int accumulate) {
+  const int nq = N >> 2;
+  const long long total = (long long)M * nq;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nq), q = (int)(i % nq);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + k * stride + (long long)m * N + q * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + q * 4);
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(C + (size_t)m * ldc + q * 4);
+    if (accumulate) {
+      const float4 o = *dst;
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    if (relu) {
+      s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f);
+    }
+    *dst = s;
+  }
+}
+
+template <int AKM, int BKM, int BM, int BN, int WM, int WN>
+int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
+  GemmParams p;
+  p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias;
+  p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+  p.M = d.M; p.N = d.N; p.K = d.K;
+  p.relu = d.relu; p.accumulate = d.accumulate;
+  const int tiles_m = cdiv(d.M, BM);
+  p.tiles_n = cdiv(d.N, BN);
+  p.nblk = tiles_m * p.tiles_n;
+
+  // split the reduction when the output alone cannot fill the chip (the
+  // weight-gradient products: small [out][in] result, reduction over all rows)
+  int splits = 1;
+  if (p.nblk < 256 && d.K >= 2048 && ws) {
+    splits = min(cdiv(768, p.nblk), d.K / 512);
+    const size_t slab = (size_t)d.M * d.N * sizeof(float);
+    if (slab == 0) return DVAE_OK;
+    splits = (int)min((size_t)splits, ws_bytes / slab);
+    if (splits < 2 || (d.N & 3)) splits = 1;
+  }
+  p.k_chunk = round_up(cdiv(d.K, splits), BK);
+  splits = cdiv(d.K, p.k_chunk);
+  if (splits > 1) {
+    p.C = ws; p.ldc = d.N; p.c_split = (long long)d.M * d.N;
+    p.bias = nullptr; p.relu = 0; p.accumulate = 0;
+  } else {
+    p.c_split = 0;
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN>), dim3(p.nblk, splits), dim3(256), 0,
+                     stream, p);
+  DVAE_LAUNCH_CHECK();
+  if (splits > 1) {
+    const long long total = (long long)d.M * (d.N / 4);
+    const int grid = (int)min((long long)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, ws, splits,
+                       (long long)d.M * d.N, d.C, d.ldc, d.M, d.N, d.bias, d.relu, d.accumulate);
+    DVAE_LAUNCH_CHECK();
+  }
+  return DVAE_OK;
+}
+
+}  // namespace
+
+int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
+  if (d.M <= 0 || d.N <= 0) return DVAE_OK;
+  DVAE_REQUIRE(d.K > 0, "gemm: K must be positive");
+  DVAE_REQUIRE(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0, "gemm: operands must be 16-byte aligned");
+  DVAE_REQUIRE((d.lda & 3) == 0 && (d.ldb & 3) == 0, "gemm: leading dimensions must be multiples of 4");
+  // the contiguous extent of every operand is loaded as float4
+  if (!d.a_kmajor) DVAE_REQUIRE((d.K & 3) == 0, "gemm: K must be a multiple of 4 for an m-major A");
+  else DVAE_REQUIRE((d.M & 3) == 0, "gemm: M must be a multiple of 4 for a k-major A");
+  if (!d.b_kmajor) DVAE_REQUIRE((d.K & 3) == 0, "gemm: K must be a multiple of 4 for an n-major B");
+  else DVAE_REQUIRE((d.N & 3) == 0, "gemm: N must be a multiple of 4 for a k-major B");
+  const bool narrow = d.N <= 32;
+  if (!d.a_kmajor && !d.b_kmajor)
+    return narrow ? launch<0, 0, 128, 32, 4, 1>(d, ws, ws_bytes, stream)
+                  : launch<0, 0, 128, 128, 2, 2>(d, ws, ws_bytes, stream);
+  if (!d.a_kmajor && d.b_kmajor)
+    return narrow ? launch<0, 1, 128, 32, 4, 1>(d, ws, ws_bytes, stream)
+                  : launch<0, 1, 128, 128, 2, 2>(d, ws, ws_bytes, stream);
+  if (d.a_kmajor && d.b_kmajor)
+    return narrow ? launch<1, 1, 128, 32, 4, 1>(d, ws, ws_bytes, stream)
+                  : launch<1, 1, 128, 128, 2, 2>(d, ws, ws_bytes, stream);
+  dvae_set_error("gemm: layout a_kmajor=1,b_kmajor=0 is not used by this library");
+  return DVAE_ERR_ARG;
+}
+
+extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
+                             int b_kmajor, float* C, int ldc, int M, int N, int K, const float* bias,
+                             int relu, int accumulate, float* ws, size_t ws_bytes, void* stream) {
+  GemmDesc d;
+  d.A = A; d.lda = lda; d.a_kmajor = a_kmajor;
+  d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
+  d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
+  d.bias = bias; d.relu = relu; d.accumulate = accumulate;
+  return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,102 @@
+// Launchers of the bandwidth-bound kernels of the D-VAE path (kernels.hip).
+// Tables are row-major with a row stride of HP floats (HP % 64 == 0); a work item
+// is one float4 of one row.
+#pragma once
+#include "common.h"
+#include "sched.h"
+
+// packed weights of one GRUCell: Whh [3HP][HP] | WihT [C][3HP] | bih [3HP] | bhh [3HP]
+struct GruW {
+  const float* Whh; const float* WihT; const float* bih; const float* bhh;
+};
+static inline size_t gru_floats(int HP, int C) { return (size_t)3 * HP * HP + (size_t)C * 3 * HP + 6 * HP; }
+static inline GruW gru_at(const float* p, int HP, int C) {
+  GruW w;
+  w.Whh = p; w.WihT = p + (size_t)3 * HP * HP; w.bih = w.WihT + (size_t)C * 3 * HP; w.bhh = w.bih + 3 * HP;
+  return w;
+}
+// gate/map pair, mod None: Wgm [2HP][HP] | posb [npos][2HP]
+//                mod bn  : WgmT [C][2HP] | bgm [2HP]
+static inline size_t gm_floats(int HP, int C, int npos, int mod) {
+  return mod == 0 ? (size_t)2 * HP * HP + (size_t)npos * 2 * HP : (size_t)C * 2 * HP + 2 * HP;
+}
+
+// One level sweep's tables (encoder forward, encoder reverse, decoder).
+struct SweepBufs {
+  int prefix;       // 1: decoder (one row per (node, prefix length k)); 0: one row per node
+  int RH;           // rows of the h-tables: R (+E when prefix)
+  float* AGG;       // [RH][HP]  h_in of every row
+  float* GH;        // [RH][3HP] hidden GEMM -> (r,z,n) after gru_fwd -> dgh after gru_bwd
+  float* GHN;       // [RH][HP]  W_hn h + b_hn -> d n_pre after gru_bwd
+  float* HV;        // [RH][HP]  GRU outputs (== Hn when !prefix)
+  float* Hn;        // [R][HP]   final node states
+  float* GMP;       // [R][2HP]  gate/map pre-activations -> (g,m) -> their grads
+  float* GM;        // [R][HP]   g*m
+  float* DH;        // [RH][HP]  dL/dHV -> dL/dAGG after gru_bwd
+  float* DHn;       // [R][HP]   prefix only: extra gradient of the final states
+};
+
+int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st);
+int k_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+              const GruW& w, int HP, hipStream_t st);
+int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st);
+int k_gm_bn_fwd(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C,
+                const float* WgmT, const float* bgm, int HP, hipStream_t st);
+// with_gm_grad=0 (mod bn): only gathers dGM into GMP[:, :HP] scaled for the weight grads
+int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
+int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st);
+// out = dWihT | dbih | dbhh (contiguous, (C+2)*3HP floats), reduced over all RH rows
+int k_gru_wgrad(const SchedDir& S, const SweepBufs& b, const float* x, int N, int C, int HP, float* out,
+                float* part, size_t part_floats, hipStream_t st);
+// mod None: out = dposb [npos][2HP]
+int k_gm_wgrad_pos(const SchedDir& S, int R, const SweepBufs& b, int npos, int HP, float* out, float* part,
+                   size_t part_floats, hipStream_t st);
+// mod bn: out = dWgmT [C][2HP] | dbgm [2HP]
+int k_gm_wgrad_bn(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C, int HP,
+                  float* out, float* part, size_t part_floats, hipStream_t st);
+// out[w] = sum_rows X[row][w]   (W % 4 == 0)
+int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
+             hipStream_t st);
+
+// [B][N][W] API tensors <-> node-row tables
+int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st);
+int k_dense_to_rows(const SchedDir& S, int R, const float* in, int N, int W, float* T, int ld, hipStream_t st);
+
+// encoder glue: state of each graph's last node (dvae_model.py:121 uses the loop's final hv)
+int k_take_last_fwd(const SchedDir& S, const int* sizes, int B, int N, const float* Hn, float* out, int HP,
+                    hipStream_t st);
+int k_take_last_bwd(const SchedDir& S, const int* sizes, int B, int N, const float* d_out, float* DH, int HP,
+                    hipStream_t st);
+// lin01 chain step t (dvae_model.py:119): node i = n_b-1-t of the reverse sweep
+int k_chain_cat(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* hv_t,
+                const float* Hb, float* CAT, int HP, hipStream_t st);
+int k_chain_select(const int* sizes, int B, int t, const float* hv_t, float* hv_next, int HP, hipStream_t st);
+int k_chain_mask(const int* sizes, int B, int t, float* d_next, float* d_t, int HP, hipStream_t st);
+int k_chain_scatter(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* DCAT,
+                    float* d_t, float* DHb, int HP, hipStream_t st);
+
+// decoder glue -----------------------------------------------------------------
+int k_graph_state_fwd(const SchedDir& S, int R, int N, int mod, const float* Hn, const float* h0, float* GS,
+                      int HP, hipStream_t st);
+int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int* sizes, const float* DGS,
+                      float* DHn, float* dh0, int HP, hipStream_t st);
+int k_pair_fwd(const SchedView& sv, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
+               const float* b2, float* edge_logits, int EHP, hipStream_t st);
+// DA [RH][EHP]; out = dw2 [EHP] | db2 [4]
+int k_pair_bwd_a(const SchedView& sv, int RH, const float* A, const float* Bq, const float* Cq,
+                 const float* w2, const float* d_edge, float* DA, float* out, float* part,
+                 size_t part_floats, int EHP, hipStream_t st);
+int k_pair_bwd_b(const SchedView& sv, int R, const int* sizes, const float* A, const float* Bq,
+                 const float* Cq, const float* w2, const float* d_edge, float* DBq, int EHP, hipStream_t st);
+// out[b] = sum over the graph's nodes of T[row]   (W % 4 == 0)
+int k_graph_sum(const SchedDir& S, const int* sizes, int B, int N, const float* T, int W, float* out,
+                hipStream_t st);
+// dh0[b] += DAGG[prefix row 0 of node 0 of graph b]
+int k_add_dh0(const SchedDir& S, int B, int N, const float* DAGG, float* dh0, int HP, hipStream_t st);
+
+// misc
+// out[r][c] = c < W ? in[r][c] : 0 for c < ncols (in == NULL: zeros)
+int k_pad_rows(const float* in, int rows, int W, float* out, int ld, int ncols, hipStream_t st);
+int k_relu_bwd(float* d, const float* y, size_t n, hipStream_t st);   // d *= (y > 0)
+int k_unpad_rows(const float* in, int ld, int rows, int W, float* out, hipStream_t st);
+int k_add_rows(float* dst, int ldd, const float* src, int lds_, int rows, int W, hipStream_t st);

@@ -1,0 +1,982 @@
+// Bandwidth-bound kernels of the D-VAE path: CSR gated-sum aggregation, GRU
+// gate epilogues, gate/map epilogues, their backward forms, the deterministic
+// weight-gradient column reductions, the add_edge pair scorer and glue copies.
+// No atomics anywhere: every reduction is "partials in a fixed order, then a
+// sum", so results are bitwise reproducible run to run.
+#include "kernels.h"
+
+#include <algorithm>
+
+namespace {
+
+inline dim3 grid_for(long long items, int cap = 8192) {
+  long long g = (items + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return dim3((unsigned)g);
+}
+
+#define ITEM_LOOP(total) \
+  for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < (total); it += (long long)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// aggregation: h_in = sum of gated states of the predecessors (dvae_model.py:77-80)
+// prefix mode writes every running sum (decoder suffix states, :223-241).
+// ---------------------------------------------------------------------------
+__global__ void agg_fwd_kernel(SchedDir S, int ns, int ne, int prefix, const float* __restrict__ GM,
+                               float* __restrict__ AGG, const float* __restrict__ h0, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(ne - ns) * HP4;
+  ITEM_LOOP(total) {
+    const int r = ns + (int)(it / HP4), q = (int)(it % HP4);
+    const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+    float4 acc = zero4();
+    if (!prefix) {
+      for (int t = 0; t < deg; ++t) acc = add4(acc, ld4(GM + (size_t)S.csr_idx[p + t] * HP + q * 4));
+      st4(AGG + (size_t)r * HP + q * 4, acc);
+    } else {
+      const size_t p0 = (size_t)p + r;
+      if (h0 && S.row_node[r] == 0) acc = ld4(h0 + (size_t)S.row_graph[r] * HP + q * 4);
+      st4(AGG + p0 * HP + q * 4, acc);
+      for (int t = 0; t < deg; ++t) {
+        acc = add4(acc, ld4(GM + (size_t)S.csr_idx[p + t] * HP + q * 4));
+        st4(AGG + (p0 + t + 1) * HP + q * 4, acc);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// GRUCell epilogue (gate order r,z,n; dvae_model.py:83,244).  GH holds agg.Whh^T.
+// ---------------------------------------------------------------------------
+__global__ void gru_fwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __restrict__ GH,
+                               const float* __restrict__ AGG, float* __restrict__ GHN,
+                               float* __restrict__ HV, float* __restrict__ Hn,
+                               const float* __restrict__ x, int N, int C, GruW w, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(p1 - p0) * HP4;
+  ITEM_LOOP(total) {
+    const int p = p0 + (int)(it / HP4), q = (int)(it % HP4);
+    const int r = prefix ? S.prow_node[p] : p;
+    const int b = S.row_graph[r], i = S.row_node[r];
+    const float* xr = x + ((size_t)b * N + i) * C;
+    const int j = q * 4;
+    float4 gi[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gi[g] = ld4(w.bih + g * HP + j);
+    for (int c = 0; c < C; ++c) {
+      const float xv = xr[c];
+      if (xv != 0.f) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gi[g] = fma4(xv, ld4(w.WihT + (size_t)c * 3 * HP + g * HP + j), gi[g]);
+      }
+    }
+    float* gh = GH + (size_t)p * 3 * HP;
+    const float4 ghr = add4(ld4(gh + j), ld4(w.bhh + j));
+    const float4 ghz = add4(ld4(gh + HP + j), ld4(w.bhh + HP + j));
+    const float4 ghn = add4(ld4(gh + 2 * HP + j), ld4(w.bhh + 2 * HP + j));
+    const float4 a = ld4(AGG + (size_t)p * HP + j);
+    float4 rr, zz, nn, hh;
+#define GRU_LANE(f)                                   \
+    rr.f = sigm(gi[0].f + ghr.f);                     \
+    zz.f = sigm(gi[1].f + ghz.f);                     \
+    nn.f = tanhf(gi[2].f + rr.f * ghn.f);             \
+    hh.f = (1.f - zz.f) * nn.f + zz.f * a.f;
+    GRU_LANE(x) GRU_LANE(y) GRU_LANE(z) GRU_LANE(w)
+#undef GRU_LANE
+    st4(gh + j, rr);
+    st4(gh + HP + j, zz);
+    st4(gh + 2 * HP + j, nn);
+    st4(GHN + (size_t)p * HP + j, ghn);
+    st4(HV + (size_t)p * HP + j, hh);
+    if (prefix && p == S.csr_ptr[r + 1] + r) st4(Hn + (size_t)r * HP + j, hh);
+  }
+}
+
+// gate/map epilogue, mod None: GMP holds h.[Wg;Wm][:, :H]^T; the position one-hot
+// columns and the biases come in as posb[i] (dvae_model.py:71-79)
+__global__ void gm_fwd_kernel(SchedDir S, int ns, int ne, float* __restrict__ GMP,
+                              const float* __restrict__ posb, float* __restrict__ GM, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(ne - ns) * HP4;
+  ITEM_LOOP(total) {
+    const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int i = S.row_node[r];
+    float* gp = GMP + (size_t)r * 2 * HP;
+    const float4 gpre = add4(ld4(gp + j), ld4(posb + (size_t)i * 2 * HP + j));
+    const float4 m = add4(ld4(gp + HP + j), ld4(posb + (size_t)i * 2 * HP + HP + j));
+    const float4 g = make_float4(sigm(gpre.x), sigm(gpre.y), sigm(gpre.z), sigm(gpre.w));
+    st4(gp + j, g);
+    st4(gp + HP + j, m);
+    st4(GM + (size_t)r * HP + j, make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w));
+  }
+}
+
+// mod 'bn': the gate/map input is the predecessor's node encoding only (:73-74)
+__global__ void gm_bn_fwd_kernel(SchedDir S, int R, float* __restrict__ GMP, float* __restrict__ GM,
+                                 const float* __restrict__ x, int N, int C, const float* __restrict__ WgmT,
+                                 const float* __restrict__ bgm, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)R * HP4;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
+    float4 gpre = ld4(bgm + j), m = ld4(bgm + HP + j);
+    for (int c = 0; c < C; ++c) {
+      const float xv = xr[c];
+      if (xv != 0.f) {
+        gpre = fma4(xv, ld4(WgmT + (size_t)c * 2 * HP + j), gpre);
+        m = fma4(xv, ld4(WgmT + (size_t)c * 2 * HP + HP + j), m);
+      }
+    }
+    const float4 g = make_float4(sigm(gpre.x), sigm(gpre.y), sigm(gpre.z), sigm(gpre.w));
+    float* gp = GMP + (size_t)r * 2 * HP;
+    st4(gp + j, g);
+    st4(gp + HP + j, m);
+    st4(GM + (size_t)r * HP + j, make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w));
+  }
+}
+
+// dGM of a node = sum over its consumers of dAGG (transpose CSR gather), then
+// through g*m:  GMP <- (dGM*m*g*(1-g), dGM*g)
+__global__ void dgm_bwd_kernel(SchedDir S, int ns, int ne, int prefix, const float* __restrict__ DAGG,
+                               float* __restrict__ GMP, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(ne - ns) * HP4;
+  ITEM_LOOP(total) {
+    const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    float4 d = zero4();
+    const int e0 = S.csc_ptr[r], e1 = S.csc_ptr[r + 1];
+    for (int e = e0; e < e1; ++e) {
+      if (prefix) {
+        const size_t pr = S.csc_prow[e];
+        const int cnt = S.csc_cnt[e];
+        for (int t = 0; t < cnt; ++t) d = add4(d, ld4(DAGG + (pr + t) * HP + j));
+      } else {
+        d = add4(d, ld4(DAGG + (size_t)S.csc_idx[e] * HP + j));
+      }
+    }
+    float* gp = GMP + (size_t)r * 2 * HP;
+    const float4 g = ld4(gp + j), m = ld4(gp + HP + j);
+    st4(gp + j, make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
+                            d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w)));
+    st4(gp + HP + j, make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w));
+  }
+}
+
+// GRUCell backward epilogue: GH (r,z,n) -> (dr_pre, dz_pre, dn_pre*r) = d(gh);
+// GHN -> dn_pre (so d(gi) = (GH_r, GH_z, GHN)); DH -> dh*z (direct path to h_in)
+__global__ void gru_bwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __restrict__ GH,
+                               float* __restrict__ GHN, const float* __restrict__ AGG,
+                               float* __restrict__ DH, const float* __restrict__ DHn, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(p1 - p0) * HP4;
+  ITEM_LOOP(total) {
+    const int p = p0 + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    float4 dh = ld4(DH + (size_t)p * HP + j);
+    if (prefix && DHn) {
+      const int r = S.prow_node[p];
+      if (p == S.csr_ptr[r + 1] + r) dh = add4(dh, ld4(DHn + (size_t)r * HP + j));
+    }
+    float* gh = GH + (size_t)p * 3 * HP;
+    const float4 rr = ld4(gh + j), zz = ld4(gh + HP + j), nn = ld4(gh + 2 * HP + j);
+    const float4 ghn = ld4(GHN + (size_t)p * HP + j);
+    const float4 a = ld4(AGG + (size_t)p * HP + j);
+    float4 drp, dzp, dnp, dnr, da;
+#define BWD_LANE(f)                                              \
+    dnp.f = dh.f * (1.f - zz.f) * (1.f - nn.f * nn.f);            \
+    dzp.f = dh.f * (a.f - nn.f) * zz.f * (1.f - zz.f);            \
+    drp.f = dnp.f * ghn.f * rr.f * (1.f - rr.f);                  \
+    dnr.f = dnp.f * rr.f;                                         \
+    da.f = dh.f * zz.f;
+    BWD_LANE(x) BWD_LANE(y) BWD_LANE(z) BWD_LANE(w)
+#undef BWD_LANE
+    st4(gh + j, drp);
+    st4(gh + HP + j, dzp);
+    st4(gh + 2 * HP + j, dnr);
+    st4(GHN + (size_t)p * HP + j, dnp);
+    st4(DH + (size_t)p * HP + j, da);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// deterministic column reductions for the skinny weight gradients
+// ---------------------------------------------------------------------------
+// out[k] = sum_c part[c*stride + k]
+__global__ void reduce_parts_kernel(const float* __restrict__ part, int nparts, size_t stride,
+                                    float* __restrict__ out, size_t len) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < len; k += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < nparts; ++c) s += part[c * stride + k];
+    out[k] = s;
+  }
+}
+
+int reduce_parts(const float* part, int nparts, size_t stride, float* out, size_t len, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_parts_kernel, grid_for((long long)len, 2048), dim3(256), 0, st, part, nparts,
+                     stride, out, len);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+// thread = one hidden column j; rows [chunk*rpc, ...).  Partial layout per chunk:
+// [C][3HP] dWihT | [3HP] dbih | [3HP] dbhh
+__global__ __launch_bounds__(64) void gru_wgrad_kernel(SchedDir S, int prefix, int RH, int rpc,
+                                                       const float* __restrict__ GH,
+                                                       const float* __restrict__ GHN,
+                                                       const float* __restrict__ x, int N, int C, int HP,
+                                                       float* __restrict__ part) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  const int p0 = chunk * rpc, p1 = min(RH, p0 + rpc);
+  float acc[3][DVAE_MAX_C];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int c = 0; c < DVAE_MAX_C; ++c) acc[g][c] = 0.f;
+  float bi[3] = {0.f, 0.f, 0.f};
+  float bhn = 0.f;
+  for (int p = p0; p < p1; ++p) {
+    const int r = prefix ? S.prow_node[p] : p;
+    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
+    const float* gh = GH + (size_t)p * 3 * HP;
+    const float d0 = gh[j], d1 = gh[HP + j], dhn = gh[2 * HP + j];
+    const float d2 = GHN[(size_t)p * HP + j];
+    bi[0] += d0; bi[1] += d1; bi[2] += d2; bhn += dhn;
+#pragma unroll
+    for (int c = 0; c < DVAE_MAX_C; ++c) {
+      if (c < C) {
+        const float xv = xr[c];
+        acc[0][c] = fmaf(xv, d0, acc[0][c]);
+        acc[1][c] = fmaf(xv, d1, acc[1][c]);
+        acc[2][c] = fmaf(xv, d2, acc[2][c]);
+      }
+    }
+  }
+  float* out = part + (size_t)chunk * (C + 2) * 3 * HP;
+#pragma unroll
+  for (int c = 0; c < DVAE_MAX_C; ++c)
+    if (c < C) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) out[(size_t)c * 3 * HP + g * HP + j] = acc[g][c];
+    }
+  float* ob = out + (size_t)C * 3 * HP;
+  ob[j] = bi[0]; ob[HP + j] = bi[1]; ob[2 * HP + j] = bi[2];
+  ob[3 * HP + j] = bi[0]; ob[4 * HP + j] = bi[1]; ob[5 * HP + j] = bhn;
+}
+
+// position-keyed column sums of DGMP -> dposb[npos][2HP]; LDS accumulators [npos][64]
+__global__ __launch_bounds__(64) void gm_wgrad_pos_kernel(SchedDir S, int R, int rpc,
+                                                          const float* __restrict__ DGMP, int npos, int HP,
+                                                          float* __restrict__ part) {
+  __shared__ float acc[DVAE_MAX_N][64];
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  for (int i = 0; i < npos; ++i) acc[i][threadIdx.x] = 0.f;
+  const int r0 = chunk * rpc, r1 = min(R, r0 + rpc);
+  for (int r = r0; r < r1; ++r) acc[S.row_node[r]][threadIdx.x] += DGMP[(size_t)r * 2 * HP + col];
+  float* out = part + (size_t)chunk * npos * 2 * HP;
+  for (int i = 0; i < npos; ++i) out[(size_t)i * 2 * HP + col] = acc[i][threadIdx.x];
+}
+
+// mod bn: dWgmT[c][2HP] = sum_rows x[c] * DGMP[row], dbgm = colsum
+__global__ __launch_bounds__(64) void gm_wgrad_bn_kernel(SchedDir S, int R, int rpc,
+                                                         const float* __restrict__ DGMP,
+                                                         const float* __restrict__ x, int N, int C, int HP,
+                                                         float* __restrict__ part) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  float acc[DVAE_MAX_C];
+#pragma unroll
+  for (int c = 0; c < DVAE_MAX_C; ++c) acc[c] = 0.f;
+  float bs = 0.f;
+  const int r0 = chunk * rpc, r1 = min(R, r0 + rpc);
+  for (int r = r0; r < r1; ++r) {
+    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
+    const float d = DGMP[(size_t)r * 2 * HP + col];
+    bs += d;
+#pragma unroll
+    for (int c = 0; c < DVAE_MAX_C; ++c)
+      if (c < C) acc[c] = fmaf(xr[c], d, acc[c]);
+  }
+  float* out = part + (size_t)chunk * (C + 1) * 2 * HP;
+#pragma unroll
+  for (int c = 0; c < DVAE_MAX_C; ++c)
+    if (c < C) out[(size_t)c * 2 * HP + col] = acc[c];
+  out[(size_t)C * 2 * HP + col] = bs;
+}
+
+__global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc,
+                                                    int W, float* __restrict__ part) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= W) return;
+  const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + col];
+  part[(size_t)blockIdx.y * W + col] = s;
+}
+
+// chunking: at most `maxc` chunks of at least 128 rows, bounded by the scratch
+inline void chunking(int rows, size_t per_chunk, size_t part_floats, int maxc, int* nch, int* rpc) {
+  int n = std::max(1, std::min(maxc, cdiv(rows, 128)));
+  if (per_chunk > 0) n = (int)std::max<size_t>(1, std::min<size_t>(n, part_floats / per_chunk));
+  *rpc = std::max(1, cdiv(rows, n));
+  *nch = std::max(1, cdiv(rows, *rpc));
+}
+
+// ---------------------------------------------------------------------------
+// glue
+// ---------------------------------------------------------------------------
+__global__ void rows_to_dense_kernel(SchedDir S, int R, const float* __restrict__ T, int ld,
+                                     float* __restrict__ out, int N, int W) {
+  const long long total = (long long)R * W;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / W), c = (int)(it % W);
+    out[((size_t)S.row_graph[r] * N + S.row_node[r]) * W + c] = T[(size_t)r * ld + c];
+  }
+}
+
+__global__ void dense_to_rows_kernel(SchedDir S, int R, const float* __restrict__ in, int N, int W,
+                                     float* __restrict__ T, int ld) {
+  const long long total = (long long)R * ld;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / ld), c = (int)(it % ld);
+    T[(size_t)r * ld + c] = c < W ? in[((size_t)S.row_graph[r] * N + S.row_node[r]) * W + c] : 0.f;
+  }
+}
+
+__device__ __forceinline__ int graph_size(const int* sizes, int b, int N) { return sizes ? sizes[b] : N; }
+
+__global__ void take_last_kernel(SchedDir S, const int* __restrict__ sizes, int B, int N,
+                                 const float* __restrict__ src, float* __restrict__ dst, int HP, int bwd) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)B * HP4;
+  ITEM_LOOP(total) {
+    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int n = graph_size(sizes, b, N);
+    if (n <= 0) {
+      if (!bwd) st4(dst + (size_t)b * HP + j, zero4());
+      continue;
+    }
+    const int row = S.node2row[b * N + n - 1];
+    if (!bwd) st4(dst + (size_t)b * HP + j, ld4(src + (size_t)row * HP + j));
+    else st4(dst + (size_t)row * HP + j, add4(ld4(dst + (size_t)row * HP + j), ld4(src + (size_t)b * HP + j)));
+  }
+}
+
+__global__ void chain_cat_kernel(SchedDir S, const int* __restrict__ sizes, int B, int N, int t,
+                                 const float* __restrict__ hv_t, const float* __restrict__ Hb,
+                                 float* __restrict__ CAT, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)B * HP4;
+  ITEM_LOOP(total) {
+    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int n = graph_size(sizes, b, N);
+    float4 a = zero4(), c = zero4();
+    if (t < n) {
+      a = ld4(hv_t + (size_t)b * HP + j);
+      c = ld4(Hb + (size_t)S.node2row[b * N + n - 1 - t] * HP + j);
+    }
+    st4(CAT + (size_t)b * 2 * HP + j, a);
+    st4(CAT + (size_t)b * 2 * HP + HP + j, c);
+  }
+}
+
+__global__ void chain_select_kernel(const int* __restrict__ sizes, int B, int t,
+                                    const float* __restrict__ hv_t, float* __restrict__ hv_next, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)B * HP4;
+  ITEM_LOOP(total) {
+    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    if (t >= sizes[b]) st4(hv_next + (size_t)b * HP + j, ld4(hv_t + (size_t)b * HP + j));
+  }
+}
+
+// graphs already finished at step t pass their gradient straight through
+__global__ void chain_mask_kernel(const int* __restrict__ sizes, int B, int t, float* __restrict__ d_next,
+                                  float* __restrict__ d_t, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)B * HP4;
+  ITEM_LOOP(total) {
+    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    if (t >= sizes[b]) {
+      st4(d_t + (size_t)b * HP + j, ld4(d_next + (size_t)b * HP + j));
+      st4(d_next + (size_t)b * HP + j, zero4());
+    }
+  }
+}
+
+__global__ void chain_scatter_kernel(SchedDir S, const int* __restrict__ sizes, int B, int N, int t,
+                                     const float* __restrict__ DCAT, float* __restrict__ d_t,
+                                     float* __restrict__ DHb, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)B * HP4;
+  ITEM_LOOP(total) {
+    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int n = graph_size(sizes, b, N);
+    if (t < n) {
+      st4(d_t + (size_t)b * HP + j, ld4(DCAT + (size_t)b * 2 * HP + j));
+      float* dst = DHb + (size_t)S.node2row[b * N + n - 1 - t] * HP + j;
+      st4(dst, add4(ld4(dst), ld4(DCAT + (size_t)b * 2 * HP + HP + j)));
+    }
+  }
+}
+
+// graph_state of node i: h0 (i=0) | state of node i-1 (None, :257) | sum of states < i (bn, :251-255)
+__global__ void graph_state_fwd_kernel(SchedDir S, int R, int N, int mod, const float* __restrict__ Hn,
+                                       const float* __restrict__ h0, float* __restrict__ GS, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)R * HP4;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int b = S.row_graph[r], i = S.row_node[r];
+    float4 v;
+    if (i == 0) v = ld4(h0 + (size_t)b * HP + j);
+    else if (mod == 0) v = ld4(Hn + (size_t)S.node2row[b * N + i - 1] * HP + j);
+    else {
+      v = zero4();
+      for (int u = 0; u < i; ++u) v = add4(v, ld4(Hn + (size_t)S.node2row[b * N + u] * HP + j));
+    }
+    st4(GS + (size_t)r * HP + j, v);
+  }
+}
+
+// DHn[(b,u)] = dGS of the consumers of node u's state; dh0[b] = dGS[(b,0)]
+__global__ void graph_state_bwd_kernel(SchedDir S, int R, int N, int mod, const int* __restrict__ sizes,
+                                       const float* __restrict__ DGS, float* __restrict__ DHn,
+                                       float* __restrict__ dh0, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)R * HP4;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int b = S.row_graph[r], u = S.row_node[r];
+    const int n = graph_size(sizes, b, N);
+    float4 v = zero4();
+    if (mod == 0) {
+      if (u + 1 < n) v = ld4(DGS + (size_t)S.node2row[b * N + u + 1] * HP + j);
+    } else {
+      for (int i = u + 1; i < n; ++i) v = add4(v, ld4(DGS + (size_t)S.node2row[b * N + i] * HP + j));
+    }
+    st4(DHn + (size_t)r * HP + j, v);
+    if (u == 0) st4(dh0 + (size_t)b * HP + j, ld4(DGS + (size_t)r * HP + j));
+  }
+}
+
+__global__ void graph_sum_kernel(SchedDir S, const int* __restrict__ sizes, int B, int N,
+                                 const float* __restrict__ T, int W, float* __restrict__ out) {
+  const int W4 = W >> 2;
+  const long long total = (long long)B * W4;
+  ITEM_LOOP(total) {
+    const int b = (int)(it / W4), j = (int)(it % W4) * 4;
+    const int n = graph_size(sizes, b, N);
+    float4 v = zero4();
+    for (int i = 0; i < n; ++i) v = add4(v, ld4(T + (size_t)S.node2row[b * N + i] * W + j));
+    st4(out + (size_t)b * W + j, v);
+  }
+}
+
+__global__ void add_dh0_kernel(SchedDir S, int B, int N, const float* __restrict__ DAGG,
+                               float* __restrict__ dh0, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)B * HP4;
+  ITEM_LOOP(total) {
+    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int r = S.node2row[b * N];
+    if (r < 0) continue;
+    const size_t p = (size_t)S.csr_ptr[r] + r;
+    st4(dh0 + (size_t)b * HP + j, add4(ld4(dh0 + (size_t)b * HP + j), ld4(DAGG + p * HP + j)));
+  }
+}
+
+__global__ void pad_rows_kernel(const float* __restrict__ in, int rows, int W, float* __restrict__ out, int ld,
+                                int ncols) {
+  const long long total = (long long)rows * ncols;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / ncols), c = (int)(it % ncols);
+    out[(size_t)r * ld + c] = (in && c < W) ? in[(size_t)r * W + c] : 0.f;
+  }
+}
+
+__global__ void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    if (!(y[i] > 0.f)) d[i] = 0.f;
+}
+
+__global__ void unpad_rows_kernel(const float* __restrict__ in, int ld, int rows, int W, float* __restrict__ out) {
+  const long long total = (long long)rows * W;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / W), c = (int)(it % W);
+    out[it] = in[(size_t)r * ld + c];
+  }
+}
+
+__global__ void add_rows_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds_,
+                                int rows, int W) {
+  const long long total = (long long)rows * W;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / W), c = (int)(it % W);
+    dst[(size_t)r * ldd + c] += src[(size_t)r * lds_ + c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// add_edge pair scorer (dvae_model.py:211-219):
+//   logit(i,j) = w2 . relu(A[prow(i,k)] + Bq[j] (+ Cq[b])) + b2,
+//   k = number of predecessors of i with index above j.  One wave per row.
+// ---------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, int R, const float* __restrict__ A,
+                                                       const float* __restrict__ Bq,
+                                                       const float* __restrict__ Cq,
+                                                       const float* __restrict__ w2,
+                                                       const float* __restrict__ b2,
+                                                       float* __restrict__ edge_logits) {
+  constexpr int EHP = VPL * 256;
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  float4 wv[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) wv[v] = ld4(w2 + (lane + 64 * v) * 4);
+  const float bias2 = b2[0];
+  for (int r = wid; r < R; r += nw) {
+    const int i = S.row_node[r];
+    if (i == 0) continue;
+    const int b = S.row_graph[r];
+    const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+    const size_t p0 = (size_t)p + r;
+    int t = 0, cur = -1;
+    int next_pred = deg > 0 ? S.row_node[S.csr_idx[p]] : -1;
+    float4 a[VPL], c[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) c[v] = Cq ? ld4(Cq + (size_t)b * EHP + (lane + 64 * v) * 4) : zero4();
+    for (int j = i - 1; j >= 0; --j) {
+      while (t < deg && next_pred > j) {
+        ++t;
+        next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
+      }
+      if (t != cur) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) a[v] = add4(ld4(A + (p0 + t) * EHP + (lane + 64 * v) * 4), c[v]);
+        cur = t;
+      }
+      const size_t rj = S.node2row[b * N + j];
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float4 q = add4(a[v], ld4(Bq + rj * EHP + (lane + 64 * v) * 4));
+        s = fmaf(wv[v].x, fmaxf(q.x, 0.f), s);
+        s = fmaf(wv[v].y, fmaxf(q.y, 0.f), s);
+        s = fmaf(wv[v].z, fmaxf(q.z, 0.f), s);
+        s = fmaf(wv[v].w, fmaxf(q.w, 0.f), s);
+      }
+      s = wave_sum(s);
+      if (lane == 0) edge_logits[((size_t)b * N + i) * N + j] = s + bias2;
+    }
+  }
+}
+
+// one wave per prefix row p = (i,k): pairs j in [u_{k+1}, u_k - 1]
+template <int VPL>
+__global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, int RH, const float* __restrict__ A,
+                                                         const float* __restrict__ Bq,
+                                                         const float* __restrict__ Cq,
+                                                         const float* __restrict__ w2,
+                                                         const float* __restrict__ d_edge,
+                                                         float* __restrict__ DA, float* __restrict__ part) {
+  constexpr int EHP = VPL * 256;
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  float4 wv[VPL], dw[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    wv[v] = ld4(w2 + (lane + 64 * v) * 4);
+    dw[v] = zero4();
+  }
+  float db = 0.f;
+  for (int p = wid; p < RH; p += nw) {
+    const int r = S.prow_node[p];
+    const int i = S.row_node[r], b = S.row_graph[r];
+    const int e0 = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - e0;
+    const int k = p - (e0 + r);
+    const int hi = (k == 0 ? i : S.row_node[S.csr_idx[e0 + k - 1]]) - 1;
+    const int lo = k < deg ? S.row_node[S.csr_idx[e0 + k]] : 0;
+    float4 a[VPL], da[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      da[v] = zero4();
+      a[v] = ld4(A + (size_t)p * EHP + (lane + 64 * v) * 4);
+      if (Cq) a[v] = add4(a[v], ld4(Cq + (size_t)b * EHP + (lane + 64 * v) * 4));
+    }
+    for (int j = lo; j <= hi; ++j) {
+      const float ds = d_edge[((size_t)b * N + i) * N + j];
+      const size_t rj = S.node2row[b * N + j];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float4 q = add4(a[v], ld4(Bq + rj * EHP + (lane + 64 * v) * 4));
+#define PB_LANE(f)                                   \
+        if (q.f > 0.f) {                             \
+          da[v].f = fmaf(ds, wv[v].f, da[v].f);      \
+          dw[v].f = fmaf(ds, q.f, dw[v].f);          \
+        }
+        PB_LANE(x) PB_LANE(y) PB_LANE(z) PB_LANE(w)
+#undef PB_LANE
+      }
+      db += ds;
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) st4(DA + (size_t)p * EHP + (lane + 64 * v) * 4, da[v]);
+  }
+  float* out = part + (size_t)wid * (EHP + 4);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) st4(out + (lane + 64 * v) * 4, dw[v]);
+  if (lane == 0) st4(out + EHP, make_float4(db, 0.f, 0.f, 0.f));
+}
+
+// one wave per node j: pairs (i,j) for every later node i of the same graph
+template <int VPL>
+__global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, int R, const int* __restrict__ sizes,
+                                                         const float* __restrict__ A,
+                                                         const float* __restrict__ Bq,
+                                                         const float* __restrict__ Cq,
+                                                         const float* __restrict__ w2,
+                                                         const float* __restrict__ d_edge,
+                                                         float* __restrict__ DBq) {
+  constexpr int EHP = VPL * 256;
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  float4 wv[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) wv[v] = ld4(w2 + (lane + 64 * v) * 4);
+  for (int rj = wid; rj < R; rj += nw) {
+    const int j = S.row_node[rj], b = S.row_graph[rj];
+    const int n = graph_size(sizes, b, N);
+    float4 bq[VPL], dbq[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      dbq[v] = zero4();
+      bq[v] = ld4(Bq + (size_t)rj * EHP + (lane + 64 * v) * 4);
+      if (Cq) bq[v] = add4(bq[v], ld4(Cq + (size_t)b * EHP + (lane + 64 * v) * 4));
+    }
+    for (int i = j + 1; i < n; ++i) {
+      const int ri = S.node2row[b * N + i];
+      const uint32_t* pm = sv.rowbits + ((size_t)b * N + i) * DVAE_BITW;
+      int k = 0;
+#pragma unroll
+      for (int w = 0; w < DVAE_BITW; ++w) {
+        uint32_t m = pm[w];
+        if (w < (j >> 5)) m = 0;
+        else if (w == (j >> 5)) m &= ((j & 31) == 31) ? 0u : (~0u << ((j & 31) + 1));
+        k += __popc(m);
+      }
+      const size_t pr = (size_t)S.csr_ptr[ri] + ri + k;
+      const float ds = d_edge[((size_t)b * N + i) * N + j];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float4 q = add4(bq[v], ld4(A + pr * EHP + (lane + 64 * v) * 4));
+        if (q.x > 0.f) dbq[v].x = fmaf(ds, wv[v].x, dbq[v].x);
+        if (q.y > 0.f) dbq[v].y = fmaf(ds, wv[v].y, dbq[v].y);
+        if (q.z > 0.f) dbq[v].z = fmaf(ds, wv[v].z, dbq[v].z);
+        if (q.w > 0.f) dbq[v].w = fmaf(ds, wv[v].w, dbq[v].w);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) st4(DBq + (size_t)rj * EHP + (lane + 64 * v) * 4, dbq[v]);
+  }
+}
+
+#define VPL_DISPATCH(EHP, CALL)                                                   \
+  switch ((EHP) / 256) {                                                          \
+    case 1: { constexpr int V = 1; CALL; } break;                                 \
+    case 2: { constexpr int V = 2; CALL; } break;                                 \
+    case 3: { constexpr int V = 3; CALL; } break;                                 \
+    case 4: { constexpr int V = 4; CALL; } break;                                 \
+    case 6: { constexpr int V = 6; CALL; } break;                                 \
+    case 8: { constexpr int V = 8; CALL; } break;                                 \
+    case 12: { constexpr int V = 12; CALL; } break;                               \
+    default:                                                                      \
+      dvae_set_error("pair kernels: add_edge width %d (padded) is not instantiated", (EHP)); \
+      return DVAE_ERR_ARG;                                                        \
+  }
+
+}  // namespace
+
+// ===========================================================================
+// launchers
+// ===========================================================================
+int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  hipLaunchKernelGGL(agg_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, ns, ne,
+                     b.prefix, b.GM, b.AGG, h0, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+              const GruW& w, int HP, hipStream_t st) {
+  if (p1 <= p0) return DVAE_OK;
+  hipLaunchKernelGGL(gru_fwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, p0, p1,
+                     b.prefix, b.GH, b.AGG, b.GHN, b.HV, b.Hn, x, N, C, w, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  hipLaunchKernelGGL(gm_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, ns, ne,
+                     b.GMP, posb, b.GM, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_gm_bn_fwd(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C,
+                const float* WgmT, const float* bgm, int HP, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(gm_bn_fwd_kernel, grid_for((long long)R * (HP / 4)), dim3(256), 0, st, S, R, b.GMP, b.GM,
+                     x, N, C, WgmT, bgm, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  hipLaunchKernelGGL(dgm_bwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, ns, ne,
+                     b.prefix, b.DH, b.GMP, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st) {
+  if (p1 <= p0) return DVAE_OK;
+  hipLaunchKernelGGL(gru_bwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, p0, p1,
+                     b.prefix, b.GH, b.GHN, b.AGG, b.DH, b.DHn, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_gru_wgrad(const SchedDir& S, const SweepBufs& b, const float* x, int N, int C, int HP, float* out,
+                float* part, size_t part_floats, hipStream_t st) {
+  const size_t per = (size_t)(C + 2) * 3 * HP;
+  int nch, rpc;
+  chunking(b.RH, per, part_floats, 512, &nch, &rpc);
+  DVAE_REQUIRE(part_floats >= per, "gru_wgrad: scratch too small");
+  hipLaunchKernelGGL(gru_wgrad_kernel, dim3(HP / 64, nch), dim3(64), 0, st, S, b.prefix, b.RH, rpc, b.GH, b.GHN,
+                     x, N, C, HP, part);
+  DVAE_LAUNCH_CHECK();
+  return reduce_parts(part, nch, per, out, per, st);
+}
+
+int k_gm_wgrad_pos(const SchedDir& S, int R, const SweepBufs& b, int npos, int HP, float* out, float* part,
+                   size_t part_floats, hipStream_t st) {
+  const size_t per = (size_t)npos * 2 * HP;
+  int nch, rpc;
+  chunking(R, per, part_floats, 128, &nch, &rpc);
+  DVAE_REQUIRE(part_floats >= per, "gm_wgrad_pos: scratch too small");
+  hipLaunchKernelGGL(gm_wgrad_pos_kernel, dim3(2 * HP / 64, nch), dim3(64), 0, st, S, R, rpc, b.GMP, npos, HP,
+                     part);
+  DVAE_LAUNCH_CHECK();
+  return reduce_parts(part, nch, per, out, per, st);
+}
+
+int k_gm_wgrad_bn(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C, int HP,
+                  float* out, float* part, size_t part_floats, hipStream_t st) {
+  const size_t per = (size_t)(C + 1) * 2 * HP;
+  int nch, rpc;
+  chunking(R, per, part_floats, 512, &nch, &rpc);
+  DVAE_REQUIRE(part_floats >= per, "gm_wgrad_bn: scratch too small");
+  hipLaunchKernelGGL(gm_wgrad_bn_kernel, dim3(2 * HP / 64, nch), dim3(64), 0, st, S, R, rpc, b.GMP, x, N, C, HP,
+                     part);
+  DVAE_LAUNCH_CHECK();
+  return reduce_parts(part, nch, per, out, per, st);
+}
+
+int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
+             hipStream_t st) {
+  int nch, rpc;
+  chunking(rows, (size_t)W, part_floats, 512, &nch, &rpc);
+  DVAE_REQUIRE(part_floats >= (size_t)W, "colsum: scratch too small");
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(W, 64), nch), dim3(64), 0, st, X, ld, rows, rpc, W, part);
+  DVAE_LAUNCH_CHECK();
+  return reduce_parts(part, nch, (size_t)W, out, (size_t)W, st);
+}
+
+int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(rows_to_dense_kernel, grid_for((long long)R * W), dim3(256), 0, st, S, R, T, ld, out, N, W);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_dense_to_rows(const SchedDir& S, int R, const float* in, int N, int W, float* T, int ld, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(dense_to_rows_kernel, grid_for((long long)R * ld), dim3(256), 0, st, S, R, in, N, W, T, ld);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_take_last_fwd(const SchedDir& S, const int* sizes, int B, int N, const float* Hn, float* out, int HP,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(take_last_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, S, sizes, B, N, Hn,
+                     out, HP, 0);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_take_last_bwd(const SchedDir& S, const int* sizes, int B, int N, const float* d_out, float* DH, int HP,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(take_last_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, S, sizes, B, N,
+                     d_out, DH, HP, 1);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_chain_cat(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* hv_t,
+                const float* Hb, float* CAT, int HP, hipStream_t st) {
+  hipLaunchKernelGGL(chain_cat_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, Srev, sizes, B, N, t,
+                     hv_t, Hb, CAT, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_chain_select(const int* sizes, int B, int t, const float* hv_t, float* hv_next, int HP, hipStream_t st) {
+  if (!sizes) return DVAE_OK;
+  hipLaunchKernelGGL(chain_select_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, sizes, B, t, hv_t,
+                     hv_next, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_chain_mask(const int* sizes, int B, int t, float* d_next, float* d_t, int HP, hipStream_t st) {
+  if (!sizes) return DVAE_OK;
+  hipLaunchKernelGGL(chain_mask_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, sizes, B, t, d_next,
+                     d_t, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_chain_scatter(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* DCAT,
+                    float* d_t, float* DHb, int HP, hipStream_t st) {
+  hipLaunchKernelGGL(chain_scatter_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, Srev, sizes, B, N,
+                     t, DCAT, d_t, DHb, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_graph_state_fwd(const SchedDir& S, int R, int N, int mod, const float* Hn, const float* h0, float* GS,
+                      int HP, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(graph_state_fwd_kernel, grid_for((long long)R * (HP / 4)), dim3(256), 0, st, S, R, N, mod,
+                     Hn, h0, GS, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int* sizes, const float* DGS,
+                      float* DHn, float* dh0, int HP, hipStream_t st) {
+  (void)B;
+  if (R <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(graph_state_bwd_kernel, grid_for((long long)R * (HP / 4)), dim3(256), 0, st, S, R, N, mod,
+                     sizes, DGS, DHn, dh0, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_pair_fwd(const SchedView& sv, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
+               const float* b2, float* edge_logits, int EHP, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  const int grid = std::min(cdiv(R, 4), 4096);
+  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, sv, R, A, Bq, Cq, w2,
+                                       b2, edge_logits));
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_pair_bwd_a(const SchedView& sv, int RH, const float* A, const float* Bq, const float* Cq,
+                 const float* w2, const float* d_edge, float* DA, float* out, float* part,
+                 size_t part_floats, int EHP, hipStream_t st) {
+  if (RH <= 0) return DVAE_OK;
+  const size_t per = (size_t)EHP + 4;
+  int grid = std::min(cdiv(RH, 4), 512);
+  grid = (int)std::min<size_t>(grid, part_floats / (per * 4));
+  DVAE_REQUIRE(grid >= 1, "pair_bwd_a: scratch too small");
+  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_a_kernel<V>), dim3(grid), dim3(256), 0, st, sv, RH, A, Bq, Cq,
+                                       w2, d_edge, DA, part));
+  DVAE_LAUNCH_CHECK();
+  return reduce_parts(part, grid * 4, per, out, per, st);
+}
+
+int k_pair_bwd_b(const SchedView& sv, int R, const int* sizes, const float* A, const float* Bq,
+                 const float* Cq, const float* w2, const float* d_edge, float* DBq, int EHP, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  const int grid = std::min(cdiv(R, 4), 4096);
+  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_b_kernel<V>), dim3(grid), dim3(256), 0, st, sv, R, sizes, A, Bq,
+                                       Cq, w2, d_edge, DBq));
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_graph_sum(const SchedDir& S, const int* sizes, int B, int N, const float* T, int W, float* out,
+                hipStream_t st) {
+  hipLaunchKernelGGL(graph_sum_kernel, grid_for((long long)B * (W / 4)), dim3(256), 0, st, S, sizes, B, N, T, W,
+                     out);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_add_dh0(const SchedDir& S, int B, int N, const float* DAGG, float* dh0, int HP, hipStream_t st) {
+  hipLaunchKernelGGL(add_dh0_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, S, B, N, DAGG, dh0, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_pad_rows(const float* in, int rows, int W, float* out, int ld, int ncols, hipStream_t st) {
+  if (rows <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(pad_rows_kernel, grid_for((long long)rows * ncols), dim3(256), 0, st, in, rows, W, out, ld,
+                     ncols);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_relu_bwd(float* d, const float* y, size_t n, hipStream_t st) {
+  if (n == 0) return DVAE_OK;
+  hipLaunchKernelGGL(relu_bwd_kernel, grid_for((long long)n), dim3(256), 0, st, d, y, n);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_unpad_rows(const float* in, int ld, int rows, int W, float* out, hipStream_t st) {
+  if (rows <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(unpad_rows_kernel, grid_for((long long)rows * W), dim3(256), 0, st, in, ld, rows, W, out);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_add_rows(float* dst, int ldd, const float* src, int lds_, int rows, int W, hipStream_t st) {
+  if (rows <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(add_rows_kernel, grid_for((long long)rows * W), dim3(256), 0, st, dst, ldd, src, lds_, rows,
+                     W);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}

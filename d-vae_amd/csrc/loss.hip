@@ -1,0 +1,146 @@
+// Reparameterisation and the fused ELBO (values + gradients in one pass).
+// Reference: dvae_model.py:410-413 (reparamterize), :425-432 / :447-454 (losses).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                   const float* __restrict__ eps, float* __restrict__ z, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    z[i] = eps[i] * expf(0.5f * logvar[i]) + mu[i];
+}
+
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ logvar,
+                                   const float* __restrict__ eps, float* __restrict__ dmu,
+                                   float* __restrict__ dlogvar, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float g = dz[i];
+    dmu[i] = g;
+    dlogvar[i] = g * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+  }
+}
+
+// one wave per graph; partial[b] = {edge, vertex, kl}
+__global__ __launch_bounds__(64) void elbo_kernel(dvae_dims d, const float* __restrict__ el,
+                                                  const float* __restrict__ tl, const float* __restrict__ g,
+                                                  const float* __restrict__ x, const int* __restrict__ sizes,
+                                                  const float* __restrict__ mu, const float* __restrict__ lv,
+                                                  float beta, double* __restrict__ partial,
+                                                  float* __restrict__ d_edge, float* __restrict__ d_type,
+                                                  float* __restrict__ d_mu, float* __restrict__ d_lv) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int N = d.N, C = d.C, Z = d.Z;
+  const int n = sizes ? sizes[b] : N;
+  double se = 0.0, sv = 0.0, sk = 0.0;
+  // BCE-with-logits over the full n x n block (:425); entries the decoder never
+  // writes have logit 0 / target 0 and add ln2 each
+  const size_t eb = (size_t)b * N * N;
+  for (int e = lane; e < N * N; e += 64) {
+    const int i = e / N, j = e - i * N;
+    float grad = 0.f;
+    if (i < n && j < n) {
+      const float l = el[eb + e], t = g[eb + e];
+      se += (double)(fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l))));
+      grad = 1.f / (1.f + expf(-l)) - t;
+    }
+    if (d_edge) d_edge[eb + e] = grad;
+  }
+  // -sum log_softmax(type_logits) * x  (:427-429)
+  for (int i = lane; i < N; i += 64) {
+    const float* t = tl + ((size_t)b * N + i) * C;
+    const float* xr = x + ((size_t)b * N + i) * C;
+    if (i < n) {
+      float m = t[0];
+      for (int c = 1; c < C; ++c) m = fmaxf(m, t[c]);
+      float s = 0.f, xs = 0.f;
+      for (int c = 0; c < C; ++c) { s += expf(t[c] - m); xs += xr[c]; }
+      const float lse = m + logf(s);
+      for (int c = 0; c < C; ++c) {
+        sv += (double)(xr[c] * (lse - t[c]));
+        if (d_type) d_type[((size_t)b * N + i) * C + c] = expf(t[c] - lse) * xs - xr[c];
+      }
+    } else if (d_type) {
+      for (int c = 0; c < C; ++c) d_type[((size_t)b * N + i) * C + c] = 0.f;
+    }
+  }
+  // KL (:431)
+  for (int k = lane; k < Z; k += 64) {
+    const float m = mu[(size_t)b * Z + k], l = lv[(size_t)b * Z + k];
+    const float ex = expf(l);
+    sk += (double)(-0.5f * (1.f + l - m * m - ex));
+    if (d_mu) {
+      d_mu[(size_t)b * Z + k] = beta * m;
+      d_lv[(size_t)b * Z + k] = beta * 0.5f * (ex - 1.f);
+    }
+  }
+  se = wave_sum_d(se); sv = wave_sum_d(sv); sk = wave_sum_d(sk);
+  if (lane == 0) {
+    partial[(size_t)b * 3 + 0] = se;
+    partial[(size_t)b * 3 + 1] = sv;
+    partial[(size_t)b * 3 + 2] = sk;
+  }
+}
+
+__global__ __launch_bounds__(256) void elbo_final_kernel(const double* __restrict__ partial, int B, float beta,
+                                                         float* __restrict__ out4) {
+  __shared__ double sh[3][4];
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < B; b += 256)
+    for (int k = 0; k < 3; ++k) s[k] += partial[(size_t)b * 3 + k];
+  for (int k = 0; k < 3; ++k) s[k] = wave_sum_d(s[k]);
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; ++k) sh[k][threadIdx.x >> 6] = s[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[3];
+    for (int k = 0; k < 3; ++k) t[k] = sh[k][0] + sh[k][1] + sh[k][2] + sh[k][3];
+    out4[0] = (float)t[0];
+    out4[1] = (float)t[1];
+    out4[2] = (float)t[2];
+    out4[3] = (float)(t[0] + t[1] + (double)beta * t[2]);
+  }
+}
+
+}  // namespace
+
+extern "C" int dvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n,
+                                void* stream) {
+  if (n <= 0) return DVAE_OK;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, z, n);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+extern "C" int dvae_reparam_bwd(const float* d_z, const float* logvar, const float* eps, float* d_mu,
+                                float* d_logvar, long long n, void* stream) {
+  if (n <= 0) return DVAE_OK;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_z, logvar, eps, d_mu,
+                     d_logvar, n);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+extern "C" size_t dvae_elbo_ws_bytes(int B) { return (size_t)B * 3 * sizeof(double) + 256; }
+
+extern "C" int dvae_elbo(const dvae_dims* d, const float* edge_logits, const float* type_logits, const float* g,
+                         const float* x, const int* sizes, const float* mu, const float* logvar, float beta,
+                         float* out4, void* partial, float* d_edge, float* d_type, float* d_mu,
+                         float* d_logvar, void* stream) {
+  DVAE_REQUIRE(d && edge_logits && type_logits && g && x && mu && logvar && out4 && partial, "elbo: null pointer");
+  DVAE_REQUIRE((d_mu == nullptr) == (d_logvar == nullptr), "elbo: d_mu and d_logvar go together");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(elbo_kernel, dim3(d->B), dim3(64), 0, st, *d, edge_logits, type_logits, g, x, sizes, mu,
+                     logvar, beta, (double*)partial, d_edge, d_type, d_mu, d_logvar);
+  DVAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(elbo_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, d->B, beta, out4);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}

@@ -1,0 +1,35 @@
+// Device-side view of the level schedule built by dvae_sched_build().
+#pragma once
+#include "common.h"
+
+// One sweep direction.  "Predecessor" means the nodes whose gated states are
+// summed into a node: columns of its adjacency row for the forward sweep
+// (dvae_model.py:67), rows of its adjacency column for the reverse sweep (:90,97).
+struct SchedDir {
+  int* level;      // [B*N]   level per node, -1 for nodes beyond sizes[b]
+  int* node2row;   // [B*N]   node row (nodes sorted by (level, graph, index)), -1 if absent
+  int* pos;        // [N*B+1] first node row of (level L, graph b) at [L*B+b]; [N*B] = R
+  int* row_graph;  // [RM]
+  int* row_node;   // [RM]
+  int* csr_ptr;    // [RM+1]  predecessor list bounds (lists in DESCENDING node index)
+  int* csc_ptr;    // [RM+1]  successor list bounds
+  int* csr_idx;    // [EM]    node row of each predecessor
+  int* csc_idx;    // [EM]    node row of each successor
+  int* csc_prow;   // [EM]    forward only: first decoder prefix row of the successor that
+                   //         includes this node, = prow(succ, t)
+  int* csc_cnt;    // [EM]    forward only: how many prefix rows of the successor include it
+  int* prow_node;  // [RM+EM] forward only: node row of each decoder prefix row
+};
+
+struct SchedView {
+  int B, N, RM, EM;
+  uint32_t* rowbits;  // [B*N*4] bit u of row i set <=> edge u->i
+  uint32_t* colbits;  // [B*N*4] bit u of row i set <=> edge i->u
+  int* err;           // [1]
+  int* scan_tmp;      // tile sums for the scan
+  int* info;          // [DVAE_SCHED_INFO_INTS(N)] device copy of info_host
+  SchedDir dir[2];    // 0 forward, 1 reverse
+};
+
+// decoder prefix rows of node row r: prow(r,k) = csr_ptr[r] + r + k, k = 0..deg(r)
+SchedView sched_view(void* base, int B, int N);

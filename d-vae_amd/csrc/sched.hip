@@ -1,0 +1,394 @@
+// Level scheduler: dense [B,N,N] fp32 adjacency -> per-level node rows, CSR/CSC.
+// Integer work only; every output is a deterministic function of the input
+// (rows are ordered by (level, graph, node index)), so it is bit-exact against
+// oracle/levels.py.  One 64-lane wave per graph; adjacency rows live in LDS as
+// 128-bit masks.
+#include "sched.h"
+
+namespace {
+
+constexpr int SCAN_TILE = 2048;  // ints per 256-thread block
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Carver {
+  char* base; size_t off;
+  template <typename T> T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off = align_up(off + n * sizeof(T));
+    return p;
+  }
+};
+
+SchedView carve(void* base, int B, int N, size_t* total) {
+  SchedView v;
+  v.B = B; v.N = N;
+  v.RM = B * N;
+  v.EM = (int)((long long)B * N * (N - 1) / 2);
+  if (v.EM < 1) v.EM = 1;
+  Carver c{(char*)base, 0};
+  v.rowbits = c.take<uint32_t>((size_t)B * N * DVAE_BITW);
+  v.colbits = c.take<uint32_t>((size_t)B * N * DVAE_BITW);
+  v.err = c.take<int>(64);
+  v.scan_tmp = c.take<int>((size_t)cdiv(v.RM + N + 2, SCAN_TILE) + 64);
+  v.info = c.take<int>(DVAE_SCHED_INFO_INTS(N));
+  for (int d = 0; d < 2; ++d) {
+    SchedDir& s = v.dir[d];
+    s.level = c.take<int>(v.RM);
+    s.node2row = c.take<int>(v.RM);
+    s.pos = c.take<int>((size_t)N * B + 1);
+    s.row_graph = c.take<int>(v.RM);
+    s.row_node = c.take<int>(v.RM);
+    s.csr_ptr = c.take<int>(v.RM + 1);
+    s.csc_ptr = c.take<int>(v.RM + 1);
+    s.csr_idx = c.take<int>(v.EM);
+    s.csc_idx = c.take<int>(v.EM);
+    if (d == 0) {
+      s.csc_prow = c.take<int>(v.EM);
+      s.csc_cnt = c.take<int>(v.EM);
+      s.prow_node = c.take<int>((size_t)v.RM + v.EM);
+    } else {
+      s.csc_prow = nullptr; s.csc_cnt = nullptr; s.prow_node = nullptr;
+    }
+  }
+  if (total) *total = c.off;
+  return v;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ bool bit_of(const uint32_t* w, int u) { return (w[u >> 5] >> (u & 31)) & 1u; }
+
+// ---- K1: bit matrices, levels in both directions, per-(level,graph) counts --
+__global__ __launch_bounds__(64) void sched_levels_kernel(const float* __restrict__ g,
+                                                          const int* __restrict__ sizes, SchedView s,
+                                                          int want_rev) {
+  __shared__ uint32_t rowb[DVAE_MAX_N][DVAE_BITW];
+  __shared__ uint32_t colb[DVAE_MAX_N][DVAE_BITW];
+  __shared__ int lf[DVAE_MAX_N], lr[DVAE_MAX_N];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int N = s.N, B = s.B;
+  int n = sizes ? sizes[b] : N;
+  bool bad = false;
+  if (n < 0 || n > N) { bad = true; n = max(0, min(n, N)); }
+  for (int i = lane; i < DVAE_MAX_N * DVAE_BITW; i += 64) {
+    (&rowb[0][0])[i] = 0u;
+    (&colb[0][0])[i] = 0u;
+  }
+  __syncthreads();
+  const float* gb = g + (size_t)b * N * N;
+  const int total = N * N;
+  for (int e = lane; e < total; e += 64) {
+    const float v = gb[e];
+    if (v != 0.f) {
+      const int i = e / N, u = e - i * N;
+      if (v != 1.f || u >= i || i >= n) bad = true;
+      else {
+        atomicOr(&rowb[i][u >> 5], 1u << (u & 31));
+        atomicOr(&colb[u][i >> 5], 1u << (i & 31));
+      }
+    }
+  }
+  __syncthreads();
+  // forward levels: ascending index order
+  for (int i = 0; i < n; ++i) {
+    int v = 0;
+    if (lane < i && bit_of(rowb[i], lane)) v = lf[lane] + 1;
+    if (lane + 64 < i && bit_of(rowb[i], lane + 64)) v = max(v, lf[lane + 64] + 1);
+    v = wave_max(v);
+    if (lane == 0) lf[i] = v;
+    __syncthreads();
+  }
+  // reverse levels: descending index order, successors act as predecessors
+  if (want_rev) {
+    for (int i = n - 1; i >= 0; --i) {
+      int v = 0;
+      if (lane > i && lane < n && bit_of(colb[i], lane)) v = lr[lane] + 1;
+      if (lane + 64 > i && lane + 64 < n && bit_of(colb[i], lane + 64)) v = max(v, lr[lane + 64] + 1);
+      v = wave_max(v);
+      if (lane == 0) lr[i] = v;
+      __syncthreads();
+    }
+  }
+  for (int i = lane; i < N; i += 64) {
+    s.dir[0].level[b * N + i] = i < n ? lf[i] : -1;
+    if (want_rev) s.dir[1].level[b * N + i] = i < n ? lr[i] : -1;
+#pragma unroll
+    for (int w = 0; w < DVAE_BITW; ++w) {
+      s.rowbits[((size_t)b * N + i) * DVAE_BITW + w] = rowb[i][w];
+      s.colbits[((size_t)b * N + i) * DVAE_BITW + w] = colb[i][w];
+    }
+  }
+  // histogram: cnt[L*B + b] = nodes of this graph at level L
+  for (int L = lane; L < N; L += 64) {
+    int cf = 0, cr = 0;
+    for (int i = 0; i < n; ++i) {
+      cf += (lf[i] == L);
+      if (want_rev) cr += (lr[i] == L);
+    }
+    s.dir[0].pos[(size_t)L * B + b] = cf;
+    if (want_rev) s.dir[1].pos[(size_t)L * B + b] = cr;
+  }
+  // a single lane may have seen the bad entry
+  if (__any(bad) && lane == 0) atomicOr(s.err, 1);
+}
+
+// ---- exclusive scan of n ints (out may alias in), out[n] = total ------------
+__global__ __launch_bounds__(256) void scan_tile_kernel(const int* in, int* out, int n, int* tile_sums) {
+  __shared__ int wsum[4];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+  int v[8];
+  int t = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = (base + k) < n ? in[base + k] : 0;
+    t += v[k];
+  }
+  // inclusive scan of t across the block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = t;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(inc, o);
+    if (lane >= o) inc += y;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wsum[w];
+  int run = woff + inc - t;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if ((base + k) < n) out[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 255) tile_sums[blockIdx.x] = woff + inc;
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(int* tile_sums, int ntiles, int* total_out) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int t = i < ntiles ? tile_sums[i] : 0;
+    int inc = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(inc, o);
+      if (lane >= o) inc += y;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = carry_s;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    if (i < ntiles) tile_sums[i] = woff + inc - t;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ __launch_bounds__(256) void scan_add_kernel(int* out, int n, const int* tile_sums) {
+  const int off = tile_sums[blockIdx.x];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if ((base + k) < n) out[base + k] += off;
+}
+
+int exclusive_scan(const int* in, int* out, int n, int* tmp, hipStream_t st) {
+  const int ntiles = cdiv(n, SCAN_TILE);
+  hipLaunchKernelGGL(scan_tile_kernel, dim3(ntiles), dim3(256), 0, st, in, out, n, tmp);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, tmp, ntiles, out + n);
+  hipLaunchKernelGGL(scan_add_kernel, dim3(ntiles), dim3(256), 0, st, out, n, tmp);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+// ---- K3: node rows ------------------------------------------------------------
+__global__ __launch_bounds__(64) void sched_assign_kernel(SchedView s, int d) {
+  __shared__ int lv[DVAE_MAX_N];
+  const int b = blockIdx.x, lane = threadIdx.x, N = s.N, B = s.B;
+  SchedDir& S = s.dir[d];
+  for (int i = lane; i < N; i += 64) lv[i] = S.level[b * N + i];
+  __syncthreads();
+  const uint32_t* predb = d == 0 ? s.rowbits : s.colbits;
+  const uint32_t* succb = d == 0 ? s.colbits : s.rowbits;
+  for (int i = lane; i < N; i += 64) {
+    const int L = lv[i];
+    int row = -1;
+    if (L >= 0) {
+      int rank = 0;
+      for (int j = 0; j < i; ++j) rank += (lv[j] == L);
+      row = S.pos[(size_t)L * B + b] + rank;
+      S.row_graph[row] = b;
+      S.row_node[row] = i;
+      int deg = 0, out = 0;
+#pragma unroll
+      for (int w = 0; w < DVAE_BITW; ++w) {
+        deg += __popc(predb[((size_t)b * N + i) * DVAE_BITW + w]);
+        out += __popc(succb[((size_t)b * N + i) * DVAE_BITW + w]);
+      }
+      S.csr_ptr[row] = deg;   // scanned in place afterwards
+      S.csc_ptr[row] = out;
+    }
+    S.node2row[b * N + i] = row;
+  }
+}
+
+// ---- K5: CSR / CSC contents ------------------------------------------------------
+__global__ __launch_bounds__(64) void sched_fill_kernel(SchedView s, int d) {
+  const int b = blockIdx.x, lane = threadIdx.x, N = s.N;
+  SchedDir& S = s.dir[d];
+  const uint32_t* predb = d == 0 ? s.rowbits : s.colbits;
+  const uint32_t* succb = d == 0 ? s.colbits : s.rowbits;
+  for (int i = lane; i < N; i += 64) {
+    const int row = S.node2row[b * N + i];
+    if (row < 0) continue;
+    const uint32_t* pm = predb + ((size_t)b * N + i) * DVAE_BITW;
+    int p = S.csr_ptr[row];
+    const int deg = S.csr_ptr[row + 1] - p;
+    for (int w = DVAE_BITW - 1; w >= 0; --w) {
+      uint32_t m = pm[w];
+      while (m) {
+        const int bit = 31 - __clz(m);
+        m &= ~(1u << bit);
+        S.csr_idx[p++] = S.node2row[b * N + w * 32 + bit];
+      }
+    }
+    if (d == 0) {
+      const int p0 = S.csr_ptr[row] + row;
+      for (int k = 0; k <= deg; ++k) S.prow_node[p0 + k] = row;
+    }
+    // successors of node i, ascending index
+    const uint32_t* sm = succb + ((size_t)b * N + i) * DVAE_BITW;
+    int q = S.csc_ptr[row];
+    for (int w = 0; w < DVAE_BITW; ++w) {
+      uint32_t m = sm[w];
+      while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= ~(1u << bit);
+        const int j = w * 32 + bit;           // successor node index
+        const int rj = S.node2row[b * N + j];
+        S.csc_idx[q] = rj;
+        if (d == 0) {
+          // t = 1 + number of predecessors of j with index above i
+          const uint32_t* pj = predb + ((size_t)b * N + j) * DVAE_BITW;
+          int above = 0;
+          for (int ww = 0; ww < DVAE_BITW; ++ww) {
+            uint32_t mm = pj[ww];
+            if (ww < (i >> 5)) mm = 0;
+            else if (ww == (i >> 5)) mm &= ((i & 31) == 31) ? 0u : (~0u << ((i & 31) + 1));
+            above += __popc(mm);
+          }
+          const int degj = S.csr_ptr[rj + 1] - S.csr_ptr[rj];
+          const int t = above + 1;
+          S.csc_prow[q] = S.csr_ptr[rj] + rj + t;
+          S.csc_cnt[q] = degj - t + 1;
+        }
+        ++q;
+      }
+    }
+  }
+}
+
+__global__ void sched_info_kernel(SchedView s, int want_rev) {
+  // single thread: tiny
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int N = s.N, B = s.B;
+  int* info = s.info;
+  const int R = s.dir[0].pos[(size_t)N * B];
+  info[0] = *s.err;
+  info[1] = R;
+  info[2] = s.dir[0].csr_ptr[s.RM];
+  for (int d = 0; d < 2; ++d) {
+    int* ls = info + 8 + d * (N + 1);
+    int nlev = 0;
+    if (d == 0 || want_rev) {
+      for (int L = 0; L < N; ++L) {
+        const int st = s.dir[d].pos[(size_t)L * B];
+        ls[L] = st;
+        if (st < R) nlev = L + 1;
+      }
+    } else {
+      for (int L = 0; L < N; ++L) ls[L] = R;
+    }
+    ls[N] = R;
+    info[3 + d] = nlev;
+  }
+  // forward level starts in EDGE space: csr_ptr at each level's first node row, so
+  // that decoder prefix rows of level L are [ls[L]+es[L], ls[L+1]+es[L+1])
+  int* es = info + 8 + 2 * (N + 1);
+  for (int L = 0; L <= N; ++L) es[L] = s.dir[0].csr_ptr[info[8 + L]];
+  info[5] = info[6] = info[7] = 0;
+}
+
+}  // namespace
+
+SchedView sched_view(void* base, int B, int N) { return carve(base, B, N, nullptr); }
+
+extern "C" size_t dvae_sched_bytes(int B, int N) {
+  size_t total = 0;
+  carve(nullptr, B, N, &total);
+  return total;
+}
+
+extern "C" int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_reverse,
+                                void* sched, int* info_host, void* stream) {
+  DVAE_REQUIRE(B > 0 && N > 0 && N <= DVAE_MAX_N, "sched: need B>0 and 0<N<=%d (got B=%d N=%d)",
+               DVAE_MAX_N, B, N);
+  DVAE_REQUIRE((long long)B * N < (1ll << 30), "sched: B*N too large");
+  DVAE_REQUIRE(g && sched && info_host, "sched: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  SchedView s = sched_view(sched, B, N);
+  DVAE_CHECK_HIP(hipMemsetAsync(s.err, 0, sizeof(int), st));
+  hipLaunchKernelGGL(sched_levels_kernel, dim3(B), dim3(64), 0, st, g, sizes, s, want_reverse);
+  DVAE_LAUNCH_CHECK();
+  for (int d = 0; d < (want_reverse ? 2 : 1); ++d) {
+    SchedDir& S = s.dir[d];
+    DVAE_TRY(exclusive_scan(S.pos, S.pos, N * B, s.scan_tmp, st));
+    DVAE_CHECK_HIP(hipMemsetAsync(S.csr_ptr, 0, sizeof(int) * (s.RM + 1), st));
+    DVAE_CHECK_HIP(hipMemsetAsync(S.csc_ptr, 0, sizeof(int) * (s.RM + 1), st));
+    hipLaunchKernelGGL(sched_assign_kernel, dim3(B), dim3(64), 0, st, s, d);
+    DVAE_LAUNCH_CHECK();
+    // scan over RM ints; slot [RM] receives the total, so scan the first RM only
+    DVAE_TRY(exclusive_scan(S.csr_ptr, S.csr_ptr, s.RM, s.scan_tmp, st));
+    DVAE_TRY(exclusive_scan(S.csc_ptr, S.csc_ptr, s.RM, s.scan_tmp, st));
+    hipLaunchKernelGGL(sched_fill_kernel, dim3(B), dim3(64), 0, st, s, d);
+    DVAE_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(sched_info_kernel, dim3(1), dim3(64), 0, st, s, want_reverse);
+  DVAE_LAUNCH_CHECK();
+  DVAE_CHECK_HIP(hipMemcpyAsync(info_host, s.info, sizeof(int) * DVAE_SCHED_INFO_INTS(N),
+                                hipMemcpyDeviceToHost, st));
+  return DVAE_OK;
+}
+
+extern "C" int dvae_sched_export(const void* sched, int B, int N, int which, int* out,
+                                 size_t max_ints, void* stream) {
+  SchedView s = sched_view(const_cast<void*>(sched), B, N);
+  const int* src = nullptr;
+  size_t n = 0;
+  switch (which) {
+    case 0: src = s.dir[0].level; n = s.RM; break;
+    case 1: src = s.dir[1].level; n = s.RM; break;
+    case 2: src = s.dir[0].node2row; n = s.RM; break;
+    case 3: src = s.dir[1].node2row; n = s.RM; break;
+    case 4: src = s.dir[0].csr_ptr; n = (size_t)s.RM + 1; break;
+    case 5: src = s.dir[0].csr_idx; n = s.EM; break;
+    case 6: src = s.dir[0].row_graph; n = s.RM; break;
+    case 7: src = s.dir[0].row_node; n = s.RM; break;
+    default: dvae_set_error("sched_export: unknown array %d", which); return DVAE_ERR_ARG;
+  }
+  if (n > max_ints) n = max_ints;
+  DVAE_CHECK_HIP(hipMemcpyAsync(out, src, n * sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return DVAE_OK;
+}

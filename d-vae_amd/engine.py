@@ -1,0 +1,329 @@
+"""Host-side glue between torch tensors and the C ABI: schedules, packed
+parameters, workspaces and the autograd Functions behind Encoder / Decoder /
+the ELBO.  torch is plumbing here (device memory, streams, autograd graph); all
+arithmetic of the hot path happens in libdvae_hip.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, load
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.DvaeError(
+            "%s is on %s: the D-VAE hot path runs only on a ROCm device "
+            "(there is no CPU fallback)" % (name, t.device))
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ---------------------------------------------------------------------------
+# level schedule of one batch
+# ---------------------------------------------------------------------------
+_pinned = {}
+
+
+class Schedule:
+    """Topological-level schedule of a batch of DAGs (device) + its host summary.
+
+    g [B,N,N] fp32 0/1 strictly lower-triangular, g[b,i,j]=1 <=> edge j->i
+    (reference layout, dataloader.py:75-86); sizes optional int32 [B].
+    Building it costs one stream synchronisation (level row counts are needed on
+    the host to size the per-level GEMMs).
+    """
+
+    def __init__(self, g, sizes=None, want_reverse=False):
+        _require_cuda(g, "X['graph']")
+        assert g.dim() == 3 and g.shape[1] == g.shape[2], "graph must be [B,N,N]"
+        lib = load()
+        self.g = _f32c(g)
+        self.B, self.N = int(g.shape[0]), int(g.shape[1])
+        self.sizes = None if sizes is None else sizes.detach().to(device=g.device, dtype=torch.int32).contiguous()
+        self.want_reverse = bool(want_reverse)
+        nbytes = lib.dvae_sched_bytes(self.B, self.N)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        nint = _lib.sched_info_ints(self.N)
+        key = (g.device.index, nint)
+        if key not in _pinned:
+            _pinned[key] = torch.empty(nint, dtype=torch.int32).pin_memory()
+        pin = _pinned[key]
+        check(lib.dvae_sched_build(_ptr(self.g), _ptr(self.sizes), self.B, self.N, int(self.want_reverse),
+                                   _ptr(self.buf), ctypes.c_void_p(pin.data_ptr()), _stream()))
+        torch.cuda.current_stream().synchronize()
+        self.info = pin.numpy().copy()
+        if self.info[0] != 0:
+            raise _lib.GraphError(
+                "X['graph'] must be a 0/1 strictly lower-triangular adjacency "
+                "(node index order = topological order) within each graph's size")
+        self.R, self.E = int(self.info[1]), int(self.info[2])
+        self.nlev_fwd, self.nlev_rev = int(self.info[3]), int(self.info[4])
+
+    @property
+    def info_ptr(self):
+        return ctypes.c_void_p(self.info.ctypes.data)
+
+    def export(self, which, n):
+        out = torch.empty(n, dtype=torch.int32, device=self.buf.device)
+        check(load().dvae_sched_export(_ptr(self.buf), self.B, self.N, which, _ptr(out), n, _stream()))
+        return out
+
+    def levels(self, reverse=False):
+        return self.export(1 if reverse else 0, self.B * self.N).view(self.B, self.N)
+
+
+# ---------------------------------------------------------------------------
+# packed parameters
+# ---------------------------------------------------------------------------
+class ParamPack:
+    """Zero-padded device copy of one module's parameters + the table that maps
+    reference-shaped tensors to it (and packed gradients back)."""
+
+    def __init__(self, kind):
+        assert kind in ("enc", "dec")
+        self.kind = kind
+        self.key = None
+        self.table = None
+        self.n = 0
+        self.P = None
+        self.offsets = None
+        self.total = 0
+
+    def _build(self, dims, params):
+        lib = load()
+        count = (lib.dvae_enc_param_count if self.kind == "enc" else lib.dvae_dec_param_count)(ctypes.byref(dims))
+        assert len(params) == count, "expected %d parameters, got %d" % (count, len(params))
+        raw = np.array([p.data_ptr() for p in params], dtype=np.uint64)
+        offs, o = [], 0
+        for p in params:
+            offs.append(o)
+            o += p.numel()
+        self.offsets, self.total = offs, o
+        goff = np.array(offs, dtype=np.int64)
+        host = (_lib.PackEntry * 128)()
+        fn = lib.dvae_enc_pack_table if self.kind == "enc" else lib.dvae_dec_pack_table
+        n = fn(ctypes.byref(dims), ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(goff.ctypes.data),
+               ctypes.cast(host, ctypes.c_void_p), 128)
+        if n < 0:
+            check(n)
+        self.n = n
+        dev = params[0].device
+        blob = np.frombuffer(bytes(host), dtype=np.uint8)[: n * ctypes.sizeof(_lib.PackEntry)].copy()
+        self.table = torch.from_numpy(blob).to(dev)
+        nfl = (lib.dvae_enc_param_floats if self.kind == "enc" else lib.dvae_dec_param_floats)(ctypes.byref(dims))
+        self.nfloats = int(nfl)
+        self.P = torch.zeros(self.nfloats, dtype=torch.float32, device=dev)
+
+    def pack(self, dims, params):
+        for p in params:
+            _require_cuda(p, "parameter")
+            assert p.dtype == torch.float32 and p.is_contiguous(), "parameters must be contiguous fp32"
+        key = (dims.H, dims.Z, dims.C, dims.N, dims.mod, dims.bidir, dims.npos) + tuple(p.data_ptr() for p in params)
+        if key != self.key:
+            self._build(dims, params)
+            self.key = key
+        check(load().dvae_pack_params(_ptr(self.table), self.n, _ptr(self.P), _stream()))
+        return self.P
+
+    def new_packed_grad(self):
+        return torch.zeros(self.nfloats, dtype=torch.float32, device=self.P.device)
+
+    def unpack(self, G, flat=None):
+        """packed gradient buffer -> flat reference-shaped gradients (views returned)."""
+        if flat is None:
+            flat = torch.empty(self.total, dtype=torch.float32, device=G.device)
+        check(load().dvae_unpack_grads(_ptr(self.table), self.n, _ptr(G), _ptr(flat), _stream()))
+        return flat
+
+    def views(self, flat, params):
+        return [flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, params)]
+
+
+# ---------------------------------------------------------------------------
+# raw forward / backward calls (no autograd) -- used by the Functions below and by
+# the fused train step of model.Dvae
+# ---------------------------------------------------------------------------
+def _dims_for(d0, B, N):
+    d = _lib.DvaeDims()
+    ctypes.memmove(ctypes.byref(d), ctypes.byref(d0), ctypes.sizeof(d))
+    d.B, d.N = int(B), int(N)
+    check(load().dvae_dims_init(ctypes.byref(d)))
+    return d
+
+
+class EncoderCall:
+    def __init__(self, dims, sched, x, P, want_states=False):
+        lib = load()
+        self.dims, self.sched, self.x, self.P = dims, sched, x, P
+        dev = x.device
+        B = dims.B
+        self.ws = torch.empty(lib.dvae_enc_ws_bytes(ctypes.byref(dims), sched.R, sched.E), dtype=torch.uint8, device=dev)
+        self.hv = torch.empty(B, dims.H, device=dev)
+        self.mu = torch.empty(B, dims.Z, device=dev)
+        self.logvar = torch.empty(B, dims.Z, device=dev)
+        self.states = torch.empty(B, dims.N, dims.H, device=dev) if want_states else None
+        self.states_rev = torch.empty(B, dims.N, dims.H, device=dev) if (want_states and dims.bidir) else None
+        check(lib.dvae_encoder_fwd(ctypes.byref(dims), _ptr(x), _ptr(sched.sizes), _ptr(sched.buf), sched.info_ptr,
+                                   _ptr(P), _ptr(self.ws), _ptr(self.hv), _ptr(self.mu), _ptr(self.logvar),
+                                   _ptr(self.states), _ptr(self.states_rev), _stream()))
+
+    def backward(self, d_hv, d_mu, d_logvar, G):
+        s = self.sched
+        check(load().dvae_encoder_bwd(ctypes.byref(self.dims), _ptr(self.x), _ptr(s.sizes), _ptr(s.buf), s.info_ptr,
+                                      _ptr(self.P), _ptr(self.ws), _ptr(d_hv), _ptr(d_mu), _ptr(d_logvar),
+                                      _ptr(G), _stream()))
+
+
+class DecoderCall:
+    def __init__(self, dims, sched, z, x, P, want_states=False):
+        lib = load()
+        self.dims, self.sched, self.z, self.x, self.P = dims, sched, z, x, P
+        dev = x.device
+        B, N = dims.B, dims.N
+        self.ws = torch.empty(lib.dvae_dec_ws_bytes(ctypes.byref(dims), sched.R, sched.E), dtype=torch.uint8, device=dev)
+        self.edge_logits = torch.empty(B, N, N, device=dev)
+        self.type_logits = torch.empty(B, N, dims.C, device=dev)
+        self.states = torch.empty(B, N, dims.H, device=dev) if want_states else None
+        check(lib.dvae_decoder_fwd(ctypes.byref(dims), _ptr(z), _ptr(x), _ptr(sched.sizes), _ptr(sched.buf),
+                                   sched.info_ptr, _ptr(P), _ptr(self.ws), _ptr(self.edge_logits),
+                                   _ptr(self.type_logits), _ptr(self.states), _stream()))
+
+    def backward(self, d_edge, d_type, G, want_dz=True):
+        s = self.sched
+        d_z = torch.empty_like(self.z) if want_dz else None
+        check(load().dvae_decoder_bwd(ctypes.byref(self.dims), _ptr(self.z), _ptr(self.x), _ptr(s.sizes), _ptr(s.buf),
+                                      s.info_ptr, _ptr(self.P), _ptr(self.ws), _ptr(d_edge), _ptr(d_type), _ptr(G),
+                                      _ptr(d_z), _stream()))
+        return d_z
+
+
+def elbo_call(dims, edge_logits, type_logits, g, x, sizes, mu, logvar, beta, want_grads):
+    lib = load()
+    dev = g.device
+    out4 = torch.empty(4, device=dev)
+    part = torch.empty(lib.dvae_elbo_ws_bytes(dims.B), dtype=torch.uint8, device=dev)
+    grads = (None, None, None, None)
+    if want_grads:
+        grads = (torch.empty_like(edge_logits), torch.empty_like(type_logits), torch.empty_like(mu),
+                 torch.empty_like(logvar))
+    check(lib.dvae_elbo(ctypes.byref(dims), _ptr(edge_logits), _ptr(type_logits), _ptr(g), _ptr(x), _ptr(sizes),
+                        _ptr(mu), _ptr(logvar), ctypes.c_float(beta), _ptr(out4), _ptr(part), _ptr(grads[0]),
+                        _ptr(grads[1]), _ptr(grads[2]), _ptr(grads[3]), _stream()))
+    return out4, grads
+
+
+def reparam_fwd(mu, logvar, eps):
+    z = torch.empty_like(mu)
+    check(load().dvae_reparam_fwd(_ptr(mu), _ptr(logvar), _ptr(eps), _ptr(z), mu.numel(), _stream()))
+    return z
+
+
+def reparam_bwd(d_z, logvar, eps):
+    d_mu, d_lv = torch.empty_like(d_z), torch.empty_like(d_z)
+    check(load().dvae_reparam_bwd(_ptr(d_z), _ptr(logvar), _ptr(eps), _ptr(d_mu), _ptr(d_lv), d_z.numel(), _stream()))
+    return d_mu, d_lv
+
+
+def predict_call(dims, z, P, u_type=None, u_edge=None, want_margin=False):
+    lib = load()
+    dev = z.device
+    M, N, C = dims.B, dims.N, dims.C
+    ws = torch.empty(lib.dvae_predict_ws_bytes(ctypes.byref(dims)), dtype=torch.uint8, device=dev)
+    edges = torch.empty(M, N, N, device=dev)
+    onehot = torch.empty(M, N, C, device=dev)
+    margin = torch.empty(1, device=dev) if want_margin else None
+    check(lib.dvae_decoder_predict(ctypes.byref(dims), _ptr(z), _ptr(P), _ptr(ws), _ptr(u_type), _ptr(u_edge),
+                                   _ptr(edges), _ptr(onehot), _ptr(margin), _stream()))
+    return edges, onehot, margin
+
+
+# ---------------------------------------------------------------------------
+# autograd Functions
+# ---------------------------------------------------------------------------
+class EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, sched, x, *params):
+        dims = _dims_for(module._dims, sched.B, sched.N)
+        P = module._pack.pack(dims, params)
+        call = EncoderCall(dims, sched, x, P)
+        ctx.call, ctx.module, ctx.params = call, module, params
+        return call.hv, call.mu, call.logvar
+
+    @staticmethod
+    def backward(ctx, d_hv, d_mu, d_logvar):
+        pack = ctx.module._pack
+        G = pack.new_packed_grad()
+        cont = lambda t: None if t is None else t.contiguous()
+        ctx.call.backward(cont(d_hv), cont(d_mu), cont(d_logvar), G)
+        grads = pack.views(pack.unpack(G), ctx.params)
+        ctx.call = None
+        return (None, None, None) + tuple(grads)
+
+
+class DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, sched, z, x, *params):
+        dims = _dims_for(module._dims, sched.B, sched.N)
+        P = module._pack.pack(dims, params)
+        call = DecoderCall(dims, sched, _f32c(z), x, P)
+        ctx.call, ctx.module, ctx.params = call, module, params
+        ctx.need_dz = z.requires_grad
+        return call.edge_logits, call.type_logits
+
+    @staticmethod
+    def backward(ctx, d_edge, d_type):
+        pack = ctx.module._pack
+        G = pack.new_packed_grad()
+        d_z = ctx.call.backward(d_edge.contiguous(), d_type.contiguous(), G, want_dz=True)
+        grads = pack.views(pack.unpack(G), ctx.params)
+        ctx.call = None
+        return (None, None, d_z, None) + tuple(grads)
+
+
+class ReparamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        ctx.save_for_backward(logvar, eps)
+        return reparam_fwd(mu, logvar, eps)
+
+    @staticmethod
+    def backward(ctx, d_z):
+        logvar, eps = ctx.saved_tensors
+        d_mu, d_lv = reparam_bwd(d_z.contiguous(), logvar, eps)
+        return d_mu, d_lv, None
+
+
+class ElboFn(torch.autograd.Function):
+    """(edge_logits, type_logits, mu, logvar) -> [edge_loss, vertex_loss, kl, loss]
+    with the gradients of `loss` computed in the same kernel pass."""
+
+    @staticmethod
+    def forward(ctx, dims, edge_logits, type_logits, g, x, sizes, mu, logvar, beta):
+        out4, grads = elbo_call(dims, edge_logits.contiguous(), type_logits.contiguous(), g, x, sizes,
+                                mu.contiguous(), logvar.contiguous(), beta, True)
+        ctx.save_for_backward(*grads)
+        ctx.beta = beta
+        return out4
+
+    @staticmethod
+    def backward(ctx, d_out4):
+        ge, gt, gm, gl = ctx.saved_tensors
+        # saved: d loss / d(.) with loss = edge + vertex + beta*kl, so each input's
+        # gradient comes from exactly one part
+        d = d_out4
+        sk = d[3] + (d[2] / ctx.beta if ctx.beta != 0 else 0.0)
+        return None, ge * (d[0] + d[3]), gt * (d[1] + d[3]), None, None, None, gm * sk, gl * sk, None

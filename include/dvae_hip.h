@@ -1,0 +1,198 @@
+/* C ABI of libdvae_hip.so: the gfx950 (MI355X) backend of the D-VAE hot path.
+ *
+ * The reference (eeishaan/d-vae) has no FFI: its hot path is the Python class
+ * API of dvae/models/dvae_model.py.  Each entry point below names the reference
+ * lines whose arithmetic it replaces; the Python side that mirrors the class
+ * API lives in d-vae_amd/model.py and calls these through ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the
+ *     name ends in _host; all floating point is fp32; all indices are int32.
+ *   - `stream` is a hipStream_t passed as void*.
+ *   - every function returns DVAE_OK (0) or a negative DVAE_ERR_* code and never
+ *     throws or aborts; dvae_last_error() gives the text of the calling thread's
+ *     last failure.
+ *   - no entry point allocates or frees device memory: the caller passes
+ *     workspaces whose sizes come from the *_bytes queries.
+ */
+#ifndef DVAE_HIP_H
+#define DVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  DVAE_OK = 0,
+  DVAE_ERR_ARG = -1,   /* bad argument / unsupported size */
+  DVAE_ERR_HIP = -2,   /* a HIP runtime call failed */
+  DVAE_ERR_GRAPH = -3  /* adjacency is not a 0/1 strictly lower-triangular DAG */
+};
+
+const char* dvae_last_error(void);
+int dvae_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Problem description.  Fill the first block and call dvae_dims_init().
+ * ---------------------------------------------------------------------- */
+typedef struct dvae_dims {
+  int B;      /* graphs in the batch                                          */
+  int N;      /* max nodes per graph = seq_len (dvae_model.py:55)             */
+  int C;      /* node types = num_classes                                     */
+  int H;      /* hidden_state_size (501, dvae_model.py:380)                   */
+  int Z;      /* latent_space_dim (56, dvae_model.py:16)                      */
+  int mod;    /* 0 = None, 1 = 'bn' (dvae_model.py:23,59,73)                  */
+  int bidir;  /* is_bidirectional (dvae_model.py:43,89)                       */
+  int npos;   /* position columns of the gate/map Linear = max_seq (mod None) */
+  /* derived */
+  int HP;     /* H rounded up to 64: row stride of every hidden-state table   */
+  int ZP;     /* Z rounded up to 64                                           */
+  int EH;     /* add_edge hidden width: 4H (None) / 6H (bn) (dvae_model.py:149-160) */
+  int EHP;    /* 4*HP / 6*HP                                                  */
+  int VHP;    /* 2*HP (add_vertex hidden, dvae_model.py:144-148)              */
+  int CP;     /* 32: padded class count                                       */
+} dvae_dims;
+
+int dvae_dims_init(dvae_dims* d);
+
+/* ------------------------------------------------------------------------
+ * fp32 MFMA GEMM (unit-test surface of the kernel behind every contraction):
+ * C[M][N] (+)= sum_k A(m,k) B(n,k) (+bias[n]) (relu).  a_kmajor/b_kmajor say
+ * whether the reduction index is the slow (row) index of that operand.
+ * Replaces the nn.Linear / nn.GRUCell matmuls of dvae_model.py:77-83,199-244.
+ * ---------------------------------------------------------------------- */
+int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,
+                  float* C, int ldc, int M, int N, int K, const float* bias, int relu,
+                  int accumulate, float* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Level scheduler.  The reference walks nodes in index order
+ * (dvae_model.py:63,93,196); this groups the nodes of every graph by
+ * topological depth, level(i) = 0 if pred(i) empty else 1 + max level(pred).
+ *
+ * g      [B][N][N] fp32 0/1, g[b][i][j]=1 <=> edge j->i, strictly lower-tri
+ *        (dataloader.py:75-86)
+ * sizes  [B] node counts (ragged batches) or NULL (every graph has N nodes)
+ * sched  workspace of dvae_sched_bytes(B,N) bytes, filled by the call
+ * info_host  pinned HOST int32[DVAE_SCHED_INFO_INTS(N)], valid after the
+ *        stream has been synchronised:
+ *          [0] error flag (0 ok)   [1] R = valid nodes   [2] E = edges
+ *          [3] forward level count [4] reverse level count
+ *          [8 .. 8+N]        forward level starts (node rows), [8+nlev] = R
+ *          [8+N+1 .. 8+2N+1] reverse level starts
+ *          [8+2N+2 .. 8+3N+2] forward level starts in edge space (csr_ptr there)
+ * ---------------------------------------------------------------------- */
+#define DVAE_SCHED_INFO_INTS(N) (8 + 3 * ((N) + 1))
+size_t dvae_sched_bytes(int B, int N);
+int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_reverse, void* sched,
+                     int* info_host, void* stream);
+/* copies one int32 array of the schedule to `out` (device); which:
+ * 0 level_fwd[B*N] 1 level_rev[B*N] 2 node2row_fwd[B*N] 3 node2row_rev[B*N]
+ * 4 csr_ptr_fwd[R+1] 5 csr_idx_fwd[E] 6 row_graph_fwd[R] 7 row_node_fwd[R] */
+int dvae_sched_export(const void* sched, int B, int N, int which, int* out, size_t max_ints,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
+ * Parameter packing.  Weights keep the reference's state_dict names and
+ * shapes on the torch side; the kernels read a zero-padded
+ * copy (H -> HP, gates at multiples of HP).  `raw_host` is a HOST array of
+ * DEVICE pointers in the canonical order documented in INTEGRATION.md;
+ * `grad_off_host` gives, in the same order, the float offset of each
+ * tensor's gradient inside one flat gradient buffer (-1: no gradient).
+ * ---------------------------------------------------------------------- */
+typedef struct dvae_pack_entry {
+  uint64_t raw;      /* parameter storage (device address)                  */
+  int64_t grad;      /* float offset of its gradient in the flat gradient
+                        buffer given to dvae_unpack_grads, -1 = none        */
+  uint64_t aux_raw;  /* kind 2: bias added to every position column         */
+  int64_t aux_grad;  /* float offset of that bias's gradient, -1 = none     */
+  int64_t dst_off;   /* float offset in the packed buffer                   */
+  int rows, cols;    /* block extent in the raw tensor                      */
+  int raw_ld, raw_col0;
+  int dst_ld;
+  int kind;          /* 0 copy, 1 transposed, 2 transposed + aux[r]         */
+} dvae_pack_entry;
+
+size_t dvae_enc_param_floats(const dvae_dims* d);
+size_t dvae_dec_param_floats(const dvae_dims* d);
+int dvae_enc_param_count(const dvae_dims* d);   /* raw tensors expected */
+int dvae_dec_param_count(const dvae_dims* d);
+int dvae_enc_pack_table(const dvae_dims* d, const uint64_t* raw_host, const int64_t* grad_off_host,
+                        dvae_pack_entry* table_host, int max_entries);
+int dvae_dec_pack_table(const dvae_dims* d, const uint64_t* raw_host, const int64_t* grad_off_host,
+                        dvae_pack_entry* table_host, int max_entries);
+/* table: DEVICE copy of the host table */
+int dvae_pack_params(const dvae_pack_entry* table, int n, float* packed, void* stream);
+int dvae_unpack_grads(const dvae_pack_entry* table, int n, const float* packed_grad, float* grad_flat,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
+ * Encoder (dvae_model.py:53-123): level-synchronous gated-sum aggregation +
+ * GRUCell, optional reverse sweep with the lin01 chain, mu/logvar heads.
+ *   x      [B][N][C] node encodings            P      packed encoder params
+ *   ws     dvae_enc_ws_bytes(d,R,E) bytes, kept by the caller until backward
+ *   hv,mu,logvar  outputs [B][H],[B][Z],[B][Z]
+ *   states optional [B][N][H] per-node forward states (parity tests), or NULL
+ * ---------------------------------------------------------------------- */
+size_t dvae_enc_ws_bytes(const dvae_dims* d, int R, int E);
+int dvae_encoder_fwd(const dvae_dims* d, const float* x, const int* sizes, const void* sched,
+                     const int* info_host, const float* P, void* ws, float* hv, float* mu,
+                     float* logvar, float* states, float* states_rev, void* stream);
+/* d_hv/d_mu/d_logvar: upstream gradients (any may be NULL); G: packed grads out */
+int dvae_encoder_bwd(const dvae_dims* d, const float* x, const int* sizes, const void* sched,
+                     const int* info_host, const float* P, void* ws, const float* d_hv,
+                     const float* d_mu, const float* d_logvar, float* G, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Teacher-forced decoder (dvae_model.py:178-261).
+ *   z [B][Z];  edge_logits [B][N][N] (strict lower triangle written, rest 0),
+ *   type_logits [B][N][C];  states optional [B][N][H] final node states.
+ * ---------------------------------------------------------------------- */
+size_t dvae_dec_ws_bytes(const dvae_dims* d, int R, int E);
+int dvae_decoder_fwd(const dvae_dims* d, const float* z, const float* x, const int* sizes,
+                     const void* sched, const int* info_host, const float* P, void* ws,
+                     float* edge_logits, float* type_logits, float* states, void* stream);
+int dvae_decoder_bwd(const dvae_dims* d, const float* z, const float* x, const int* sizes,
+                     const void* sched, const int* info_host, const float* P, void* ws,
+                     const float* d_edge_logits, const float* d_type_logits, float* G, float* d_z,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
+ * Reparameterise (dvae_model.py:410-413) with injected eps, and its backward.
+ * ---------------------------------------------------------------------- */
+int dvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n,
+                     void* stream);
+int dvae_reparam_bwd(const float* d_z, const float* logvar, const float* eps, float* d_mu,
+                     float* d_logvar, long long n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * ELBO (dvae_model.py:425-432, 447-454): BCE-with-logits summed over the full
+ * NxN block of each graph (n_b x n_b for ragged graphs), -sum log_softmax*x,
+ * KL.  out4 = {edge_loss, vertex_loss, kl_loss, loss} (device, 4 floats).
+ * When d_edge/d_type/d_mu/d_logvar are non-NULL the gradients of `loss` are
+ * written in the same pass (scaled by *grad_scale if non-NULL, device scalar).
+ * partial: workspace of dvae_elbo_ws_bytes(B) bytes.
+ * ---------------------------------------------------------------------- */
+size_t dvae_elbo_ws_bytes(int B);
+int dvae_elbo(const dvae_dims* d, const float* edge_logits, const float* type_logits,
+              const float* g, const float* x, const int* sizes, const float* mu,
+              const float* logvar, float beta, float* out4, void* partial, float* d_edge,
+              float* d_type, float* d_mu, float* d_logvar, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Autoregressive decode (dvae_model.py:263-362).  u_type [M][N] / u_edge
+ * [M][N][N] are injected uniforms for the stochastic mode, NULL for greedy.
+ * edges [M][N][N] 0/1, onehot [M][N][C].
+ * ---------------------------------------------------------------------- */
+size_t dvae_predict_ws_bytes(const dvae_dims* d);   /* d->B = M */
+int dvae_decoder_predict(const dvae_dims* d, const float* z, const float* P, void* ws,
+                         const float* u_type, const float* u_edge, float* edges, float* onehot,
+                         float* min_margin, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,133 @@
+"""GPU unit tests of the building blocks, each against a plain torch fp32
+reference of the same op (run on the same device)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(lib, A, a_km, Bm, b_km, M, N, K, bias=None, relu=0, acc=None, ws_mb=64):
+    from dvae_amd import engine as E
+    dev = A.device
+    C = acc.clone() if acc is not None else torch.full((M, N), float("nan"), device=dev)
+    ws = torch.empty(ws_mb << 20, dtype=torch.uint8, device=dev)
+    E.check(lib.dvae_gemm_f32(E._ptr(A), A.stride(0), a_km, E._ptr(Bm), Bm.stride(0), b_km, E._ptr(C), C.stride(0),
+                              M, N, K, E._ptr(bias), relu, int(acc is not None), E._ptr(ws), ws.numel(), E._stream()))
+    torch.cuda.synchronize()
+    return C
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (4096, 1536, 512), (1000, 1024, 512), (37, 32, 1024),
+                                   (300, 2048, 64), (5, 128, 2048)])
+def test_gemm_nt(cuda, M, N, K):
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(0)
+    A = torch.randn(M, K, device=cuda)
+    W = torch.randn(N, K, device=cuda)
+    bias = torch.randn(N, device=cuda)
+    ref = (A.double() @ W.double().t() + bias.double())
+    out = _gemm(lib, A, 0, W, 0, M, N, K, bias=bias)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
+    out = _gemm(lib, A, 0, W, 0, M, N, K, bias=bias, relu=1)
+    assert torch.allclose(out.double(), ref.clamp(min=0), rtol=1e-5, atol=1e-4 * K ** 0.5)
+
+
+def test_gemm_asymmetric_exact(cuda):
+    """A = I with an asymmetric integer B catches swapped row/col maps."""
+    from dvae_amd._lib import load
+    lib = load()
+    M = N = K = 128
+    A = torch.eye(M, device=cuda)
+    W = (torch.arange(N, device=cuda).view(N, 1) * 3 + torch.arange(K, device=cuda).view(1, K) * 7 % 11).float()
+    out = _gemm(lib, A, 0, W, 0, M, N, K)
+    assert torch.equal(out, W.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 1536), (777, 512, 1024), (64, 1024, 32), (130, 512, 2048)])
+def test_gemm_nn(cuda, M, N, K):
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(1)
+    dY = torch.randn(M, K, device=cuda)
+    W = torch.randn(K, N, device=cuda)
+    base = torch.randn(M, N, device=cuda)
+    ref = dY.double() @ W.double()
+    out = _gemm(lib, dY, 0, W, 1, M, N, K)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
+    out = _gemm(lib, dY, 0, W, 1, M, N, K, acc=base)
+    assert torch.allclose(out.double(), ref + base.double(), rtol=1e-5, atol=1e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(1536, 512, 4096), (2048, 512, 90000), (32, 1024, 5000), (1024, 512, 333),
+                                   (512, 64, 4096)])
+def test_gemm_tn(cuda, M, N, K):
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(2)
+    dY = torch.randn(K, M, device=cuda)
+    X = torch.randn(K, N, device=cuda)
+    ref = dY.double().t() @ X.double()
+    out = _gemm(lib, dY, 1, X, 1, M, N, K)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=2e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("B,N,p,ragged", [(64, 8, 0.5, False), (33, 20, 0.2, False), (16, 128, 0.05, False),
+                                          (50, 40, 0.15, True), (7, 1, 0.5, False)])
+def test_schedule_bit_exact(cuda, B, N, p, ragged):
+    """Levels (both directions), node rows and CSR against oracle/levels.py."""
+    from dvae_amd import engine as E, synth
+    from oracle import levels as OL
+    if ragged:
+        g, x, sizes = synth.ragged_dags(B, 4, 5, nmin=3, nmax=N)
+    else:
+        g, x = synth.random_dags(B, N, 4, p, 3, fix_orphans=(N > 1))
+        sizes = None
+    s = E.Schedule(g.to(cuda), None if sizes is None else sizes.to(cuda), want_reverse=True)
+    lf = s.levels(False).cpu().numpy()
+    lr = s.levels(True).cpu().numpy()
+    ef, er = OL.forward_levels(g.numpy()), OL.reverse_levels(g.numpy())
+    if sizes is not None:
+        valid = np.arange(N)[None, :] < sizes.numpy()[:, None]
+        ef = np.where(valid, ef, -1)
+        er = np.where(valid, er, -1)
+    assert np.array_equal(lf, ef)
+    assert np.array_equal(lr, er)
+    R = int((ef >= 0).sum())
+    assert s.R == R and s.E == int(g.sum())
+    assert s.nlev_fwd == int(ef.max()) + 1 and s.nlev_rev == int(er.max()) + 1
+    # rows are ordered by (level, graph, node)
+    n2r = s.export(2, B * N).cpu().numpy().reshape(B, N)
+    order = sorted((int(ef[b, i]), b, i) for b in range(B) for i in range(N) if ef[b, i] >= 0)
+    for row, (_, b, i) in enumerate(order):
+        assert n2r[b, i] == row
+    starts = s.info[8:8 + N + 1]
+    for L in range(s.nlev_fwd):
+        assert starts[L] == sum(1 for o in order if o[0] < L)
+    # CSR: predecessors in descending index order
+    ptr = s.export(4, R + 1).cpu().numpy()
+    idx = s.export(5, max(s.E, 1)).cpu().numpy()
+    preds = OL.pred_lists_desc(g.numpy())
+    for b in range(B):
+        for i in range(N):
+            if ef[b, i] < 0:
+                continue
+            r = n2r[b, i]
+            got = idx[ptr[r]:ptr[r + 1]].tolist()
+            assert got == [n2r[b, u] for u in preds[b][i]]
+
+
+def test_schedule_rejects_bad_graph(cuda):
+    from dvae_amd import engine as E
+    from dvae_amd._lib import GraphError
+    g = torch.zeros(4, 6, 6)
+    g[1, 2, 3] = 1.0       # upper triangle
+    with pytest.raises(GraphError):
+        E.Schedule(g.to(cuda))
+    g = torch.zeros(4, 6, 6)
+    g[0, 3, 1] = 0.5       # not 0/1
+    with pytest.raises(AssertionError):
+        E.Schedule(g.to(cuda))

@@ -1,0 +1,157 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs: per-node hidden states, mu/logvar, logits, the four loss
+scalars and every parameter gradient.  Tolerance: 1e-4 relative (fp32), the bar
+BASELINE.json's north_star states; gradients 3e-4 (longer reduction chains)."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from helpers import close_scaled, fill_weights, oracle_sd
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (mod, bidir, shared, H, N, C, B, p, chain)
+    "none_uni_h64": (None, False, False, 64, 8, 8, 12, 0.4, False),
+    "none_bidir_h64": (None, True, False, 64, 7, 5, 9, 0.4, False),
+    "bn_bidir_shared_h64": ("bn", True, True, 64, 10, 10, 6, 0.3, False),
+    "none_uni_h501_enas": (None, False, False, 501, 8, 8, 16, 1.0 / 3, True),
+    "none_bidir_h501": (None, True, False, 501, 8, 8, 6, 0.4, False),
+    "bn_uni_h501": ("bn", False, False, 501, 10, 10, 5, 0.3, False),
+    "none_uni_h128_n20": (None, False, False, 128, 20, 6, 5, 0.15, False),
+}
+
+
+def _make(case, cuda):
+    import dvae_amd
+    mod, bidir, shared, H, N, C, B, p, chain = CASES[case]
+    hp = Namespace(dataset_file=None, mod=mod, bidirectional=bidir, num_classes=C, max_seq=N,
+                   same_mapper_gater=shared, hidden_state_size=H)
+    model = fill_weights(dvae_amd.Dvae(hp), seed=11).to(cuda)
+    g, x = dvae_amd.synth.random_dags(B, N, C, p, seed=5, chain=chain)
+    gen = torch.Generator().manual_seed(9)
+    eps = torch.randn(B, 56, generator=gen)
+    return model, g, x, eps
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_forward_parity(cuda, case):
+    from oracle import dense_ref as O
+    mod, bidir = CASES[case][0], CASES[case][1]
+    model, g, x, eps = _make(case, cuda)
+    sd = oracle_sd(model)
+    X = {'graph': g.to(cuda), 'node_encoding': x.to(cuda)}
+    with torch.no_grad():
+        hv, mu, lv = model.encoder(X)
+        fw, bw = model.encoder.node_states(X)
+        o_hv, o_mu, o_lv, o_fw, o_bw = O.encoder_forward(sd, g, x, mod, bidir, return_states=True)
+        close_scaled(fw, o_fw, what="encoder forward states")
+        if bidir:
+            close_scaled(bw, o_bw, what="encoder reverse states")
+        close_scaled(hv, o_hv, what="hv")
+        close_scaled(mu, o_mu, what="mu")
+        close_scaled(lv, o_lv, what="logvar")
+        z = model.reparamterize(mu, lv, eps.to(cuda))
+        o_z = O.reparameterize(o_mu, o_lv, eps)
+        close_scaled(z, o_z, what="z")
+        e, t = model.decoder(o_z.to(cuda), X)
+        hd = model.decoder.node_states(o_z.to(cuda), X)
+        o_e, o_t, o_hd, _ = O.decoder_forward(sd, o_z, g, x, mod, return_states=True)
+        close_scaled(hd, o_hd, what="decoder states")
+        close_scaled(t, o_t, what="type logits")
+        close_scaled(e, o_e, what="edge logits")
+        assert torch.equal(e.cpu() != 0, torch.tril(torch.ones_like(g), -1).bool() & (e.cpu() != 0))
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_loss_and_grad_parity(cuda, case):
+    from oracle import dense_ref as O
+    mod, bidir = CASES[case][0], CASES[case][1]
+    model, g, x, eps = _make(case, cuda)
+    sd = oracle_sd(model, requires_grad=True)
+    o = O.train_loss(sd, g, x, eps, mod, bidir, beta=0.005)
+    o[0].backward()
+    X = {'graph': g.to(cuda), 'node_encoding': x.to(cuda)}
+    out = model.training_step(X, 0, eps=eps.to(cuda))
+    logs = out['log']
+    for k, ref in zip(('train/loss', 'train/edge_loss', 'train/vertex_loss', 'train/kl_loss'), o[:4]):
+        assert abs(logs[k] - float(ref)) <= 1e-4 * abs(float(ref)) + 1e-5, (k, logs[k], float(ref))
+    model.zero_grad()
+    out['loss'].backward()
+    params = dict(model.named_parameters())
+    checked = 0
+    for k, ref in sd.items():
+        if k not in params or ref.grad is None:
+            continue
+        close_scaled(params[k].grad, ref.grad, tol=3e-4, what="grad " + k)
+        checked += 1
+    assert checked == len(params)
+    # validation_step uses self.beta (dvae_model.py:454)
+    model.beta = 0.3
+    v = model.validation_step(X, 0, eps=eps.to(cuda))
+    ov = O.elbo(o[7].detach(), o[8].detach(), g, x, o[5].detach(), o[6].detach(), beta=0.3)
+    assert abs(float(v['val_loss']) - float(ov[0])) <= 1e-4 * abs(float(ov[0]))
+    # fused no-autograd step gives the same gradients
+    if not CASES[case][2]:
+        ref_grads = {k: p.grad.clone() for k, p in params.items()}
+        model.zero_grad()
+        out4 = model.loss_and_grad(X, eps=eps.to(cuda))
+        assert abs(float(out4[3]) - logs['train/loss']) <= 1e-6 * abs(logs['train/loss'])
+        for k, p in params.items():
+            assert torch.equal(p.grad, ref_grads[k]), k
+
+
+def test_ragged_parity(cuda):
+    """Mixed-size batch (beyond the reference, which forces N == max_seq); oracle
+    = per-size groups through the dense path."""
+    import dvae_amd
+    from oracle import dense_ref as O
+    H, C, Nmax, B = 64, 6, 16, 14
+    hp = Namespace(dataset_file=None, mod=None, bidirectional=True, num_classes=C, max_seq=Nmax,
+                   hidden_state_size=H)
+    model = fill_weights(dvae_amd.Dvae(hp), seed=3).to(cuda)
+    g, x, sizes = dvae_amd.synth.ragged_dags(B, C, 7, nmin=3, nmax=Nmax)
+    eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(1))
+    sd = oracle_sd(model, requires_grad=True)
+    o = O.train_loss_ragged(sd, g, x, sizes, eps, None, True)
+    o[0].backward()
+    X = {'graph': g.to(cuda), 'node_encoding': x.to(cuda), 'sizes': sizes.to(cuda)}
+    out = model.training_step(X, 0, eps=eps.to(cuda))
+    for k, ref in zip(('train/loss', 'train/edge_loss', 'train/vertex_loss', 'train/kl_loss'), o[:4]):
+        assert abs(out['log'][k] - float(ref)) <= 1e-4 * abs(float(ref)) + 1e-5, (k, out['log'][k], float(ref))
+    out['loss'].backward()
+    for k, p in model.named_parameters():
+        close_scaled(p.grad, sd[k].grad, tol=3e-4, what="grad " + k)
+
+
+@pytest.mark.parametrize("mod", [None, "bn"])
+def test_predict_parity(cuda, mod):
+    """Greedy decode must be bit-exact on graphs whose decision margins are well
+    above the fp32 noise; stochastic decode with injected uniforms likewise."""
+    import dvae_amd
+    from oracle import dense_ref as O
+    H, N, C, M = 501, 8, 8, 48
+    if mod == "bn":
+        N = C = 10
+    hp = Namespace(dataset_file=None, mod=mod, bidirectional=False, num_classes=C, max_seq=N, hidden_state_size=H)
+    model = fill_weights(dvae_amd.Dvae(hp), seed=21, scale=None).to(cuda)
+    sd = oracle_sd(model)
+    z = 3.0 * torch.randn(M, 56, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        o_edges, o_types = O.decoder_predict(sd, z, N, C, mod)
+        margins = torch.tensor([O.decoder_predict(sd, z[m:m + 1], N, C, mod, return_margin=True)[2] for m in range(M)])
+    edges, types, margin = model.decoder.predict(z.to(cuda), return_margin=True)
+    keep = margins > 2e-3
+    assert int(keep.sum()) >= M // 4, "too few graphs with a safe margin"
+    assert torch.equal(edges.cpu()[keep], o_edges[keep])
+    assert torch.equal(types.cpu()[keep], o_types[keep])
+    assert abs(float(margin) - float(margins.min())) < 1e-3
+    # stochastic, injected uniforms: compare away from decision boundaries by re-deciding
+    gen = torch.Generator().manual_seed(8)
+    u = {'type': torch.rand(M, N, generator=gen), 'edge': torch.rand(M, N, N, generator=gen)}
+    with torch.no_grad():
+        s_edges, s_types = O.decoder_predict(sd, z, N, C, mod, uniforms=u)
+    edges, types = model.decoder.predict(z.to(cuda), uniforms=(u['type'].to(cuda), u['edge'].to(cuda)))
+    same = (edges.cpu() == s_edges).flatten(1).all(1) & (types.cpu() == s_types).flatten(1).all(1)
+    assert int(same.sum()) >= M - 2, "stochastic decode differs on %d/%d graphs" % (M - int(same.sum()), M)
