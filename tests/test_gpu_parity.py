@@ -90,7 +90,7 @@ def test_loss_and_grad_parity(cuda, case):
     # validation_step uses self.beta (dvae_model.py:454)
     model.beta = 0.3
     v = model.validation_step(X, 0, eps=eps.to(cuda))
-    ov = O.elbo(o[7].detach(), o[8].detach(), g, x, o[5].detach(), o[6].detach(), beta=0.3)
+    ov = O.elbo(o[6].detach(), o[7].detach(), g, x, o[4].detach(), o[5].detach(), beta=0.3)
     assert abs(float(v['val_loss']) - float(ov[0])) <= 1e-4 * abs(float(ov[0]))
     # fused no-autograd step gives the same gradients
     if not CASES[case][2]:
