@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: DAGs/sec of a full D-VAE train step (level schedule,
+encode, reparameterise, teacher-forced decode, ELBO, backward, gradient
+all-reduce, Adam) on ENAS-like 8-node DAGs, hs=501, nz=56, global batch 4096.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the driver launches one rank per GPU through torch.distributed.run
+(RCCL); rank 0 prints ONE JSON line.  Every step sees a different pre-generated
+batch (already resident in HBM), so the schedule build is inside the timed
+region, as it would be in training.
+"""
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+from argparse import Namespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, Z, N, C = 501, 56, 8, 8
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def algorithmic_flops_per_dag(n, e):
+    """forward H^2(34N + 14E) + 12H N(N-1)/2 + 4HZ + 2ZH + 4HCN;
+    train step = 3 x forward (uni-directional, mod None)."""
+    fwd = H * H * (34 * n + 14 * e) + 12 * H * n * (n - 1) / 2 + 4 * H * Z + 2 * Z * H + 4 * H * C * n
+    return 3.0 * fwd
+
+
+def cpu_baseline(threads, seconds_budget=20.0):
+    """The reference's CPU path, restated (oracle/dense_ref.py, checked against the
+    real reference in tests/golden), timed on this box's host cores at the
+    reference's own configuration (config 1: B=32, N=8, C=8)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dvae_amd
+    from oracle import dense_ref as O
+    torch.set_num_threads(threads)
+    B = 32
+    model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=None, bidirectional=False))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
+    g, x = dvae_amd.synth.enas_like(B, 1234)
+    gen = torch.Generator().manual_seed(0)
+
+    def step():
+        eps = torch.randn(B, Z, generator=gen)
+        opt.zero_grad()
+        loss = O.train_loss(sd, g, x, eps, None, False)[0]
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 5 or (time.perf_counter() - t0 < seconds_budget and n < 200):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": B / dt, "unit": "DAGs/s", "cores": threads, "kind": "port",
+            "sample": "%d train steps (fwd+bwd+Adam) of oracle/dense_ref.py at B=32, N=8, C=8, hs=501 "
+                      "(config 1), %.0f ms/step" % (n, dt * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=4096)
+    ap.add_argument("--per-gpu-batch", type=int, default=0, help="weak scaling: fixed batch per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import dvae_amd
+    from dvae_amd import _lib
+
+    weak = args.per_gpu_batch > 0
+    B_local = args.per_gpu_batch if weak else args.global_batch // world
+    B_global = B_local * world
+
+    torch.manual_seed(0)
+    model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=None, bidirectional=False)).to(dev)
+    if world > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+
+    # a few distinct batches per rank, generated once, resident in HBM
+    nb = 4
+    batches, e_sum = [], 0.0
+    for i in range(nb):
+        g, x = dvae_amd.synth.enas_like(B_global, 100 + i)
+        sl = slice(rank * B_local, (rank + 1) * B_local)
+        e_sum += float(g[sl].sum()) / B_local
+        batches.append({'graph': g[sl].to(dev), 'node_encoding': x[sl].to(dev)})
+    mean_e = e_sum / nb
+
+    def sync_grads(flat):
+        if dist is None:
+            return None
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)   # losses are sums (dvae_model.py:405)
+
+    def step(i):
+        out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads)
+        opt.step()
+        return out4
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib = _lib.load()
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    prof = not args.no_profile
+    if prof:
+        lib.dvae_gemm_profile(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out4 = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    gemm = None
+    if prof:
+        buf = (ctypes.c_double * 12)()
+        _lib.check(lib.dvae_gemm_profile_read(ctypes.cast(buf, ctypes.c_void_p)))
+        lib.dvae_gemm_profile(0)
+        gemm = list(buf)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out4[3])
+    assert math.isfinite(loss), "loss is not finite"
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = B_global * args.steps / dt
+        res = {
+            "metric": "DAGs/sec D-VAE train step (ENAS-8node, hs=501, batch 4096)",
+            "value": value, "unit": "DAGs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if weak else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ENAS-like 8-node DAGs (chain + p=1/3), nvt=8, hs=501, nz=56, "
+                                   "uni-directional, mod=None, fwd+bwd+all-reduce+Adam",
+                       "global_batch": B_global, "per_gpu_batch": B_local, "mean_edges": round(mean_e, 2),
+                       "depth": 7, "parallelism": "dp%d" % world, "final_loss": loss},
+        }
+        if gemm is not None:
+            # dominant kernel: gemm_f32_kernel (all three layouts are one template)
+            launches = gemm[0] + gemm[3] + gemm[9]
+            kms = gemm[1] + gemm[4] + gemm[10]
+            executed = gemm[2] + gemm[5] + gemm[11]
+            algo = algorithmic_flops_per_dag(N, mean_e) * B_local * args.steps
+            ach = algo / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+            res["roofline"] = {
+                "bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": launches / args.steps, "kernel_ms_per_step": kms / args.steps,
+                "avg_launch_us": kms / max(launches, 1) * 1e3,
+                "executed_tflops": executed / (kms * 1e-3) / 1e12 if kms > 0 else 0.0,
+                "algorithmic_gflop_per_dag": algorithmic_flops_per_dag(N, mean_e) / 1e9,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

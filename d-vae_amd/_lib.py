@@ -50,6 +50,8 @@ SIGNATURES = {
     "dvae_dims_init": (c_int, [_P(DvaeDims)]),
     "dvae_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dvae_gemm_profile": (c_int, [c_int]),
+    "dvae_gemm_profile_read": (c_int, [c_void_p]),
     "dvae_sched_bytes": (c_size_t, [c_int, c_int]),
     "dvae_sched_build": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dvae_sched_export": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),

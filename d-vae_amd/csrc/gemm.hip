@@ -19,6 +19,8 @@
 //
 // The k order inside an 8-wide chunk is permuted (lane half h owns k = 4h..4h+3)
 // consistently for A and B, which only reorders the fp32 summation.
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -223,6 +225,33 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
   }
 }
 
+// ---- optional timing of every GEMM launch with HIP events on its own stream ----
+// (bench.py's roofline figures; off by default, no cost when off)
+struct GemmProf { hipEvent_t a, b; int variant; double flops; };
+struct ProfState {
+  bool on = false;
+  std::vector<GemmProf> recs;
+  size_t used = 0;
+};
+ProfState g_prof;
+
+GemmProf* prof_begin(int variant, double flops, hipStream_t st) {
+  if (!g_prof.on) return nullptr;
+  if (g_prof.used == g_prof.recs.size()) {
+    GemmProf r;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+    g_prof.recs.push_back(r);
+  }
+  GemmProf* r = &g_prof.recs[g_prof.used++];
+  r->variant = variant;
+  r->flops = flops;
+  (void)hipEventRecord(r->a, st);
+  return r;
+}
+void prof_end(GemmProf* r, hipStream_t st) {
+  if (r) (void)hipEventRecord(r->b, st);
+}
+
 template <int AKM, int BKM, int BM, int BN, int WM, int WN>
 int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   GemmParams p;
@@ -252,8 +281,10 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   } else {
     p.c_split = 0;
   }
+  GemmProf* pr = prof_begin(AKM * 2 + BKM, 2.0 * d.M * d.N * d.K, stream);
   hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN>), dim3(p.nblk, splits), dim3(256), 0,
                      stream, p);
+  prof_end(pr, stream);
   DVAE_LAUNCH_CHECK();
   if (splits > 1) {
     const long long total = (long long)d.M * (d.N / 4);
@@ -300,4 +331,25 @@ extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float*
   d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
   d.bias = bias; d.relu = relu; d.accumulate = accumulate;
   return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// variant: 0 NT, 1 NN, 3 TN.  out3[v] = {launches, milliseconds, executed flops}
+extern "C" int dvae_gemm_profile(int enable) {
+  g_prof.on = enable != 0;
+  g_prof.used = 0;
+  return DVAE_OK;
+}
+
+extern "C" int dvae_gemm_profile_read(double* out12) {
+  for (int i = 0; i < 12; ++i) out12[i] = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    GemmProf& r = g_prof.recs[i];
+    DVAE_CHECK_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    DVAE_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    double* o = out12 + 3 * (r.variant & 3);
+    o[0] += 1.0; o[1] += ms; o[2] += r.flops;
+  }
+  g_prof.used = 0;
+  return DVAE_OK;
 }

@@ -68,6 +68,13 @@ int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb
                   float* C, int ldc, int M, int N, int K, const float* bias, int relu,
                   int accumulate, float* ws, size_t ws_bytes, void* stream);
 
+/* Instrumentation for bench.py (no counterpart in the reference): while enabled,
+ * every GEMM launch is bracketed by HIP events on its own stream.
+ * dvae_gemm_profile_read waits for them and fills out12 = 4 x {launches, ms,
+ * executed flops} indexed by layout (0 NT, 1 NN, 3 TN), then clears the log. */
+int dvae_gemm_profile(int enable);
+int dvae_gemm_profile_read(double* out12_host);
+
 /* ------------------------------------------------------------------------
  * Level scheduler.  The reference walks nodes in index order
  * (dvae_model.py:63,93,196); this groups the nodes of every graph by
