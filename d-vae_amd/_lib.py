@@ -30,7 +30,8 @@ class PackEntry(ctypes.Structure):
                 ("aux_raw", ctypes.c_uint64), ("aux_grad", ctypes.c_int64),
                 ("dst_off", ctypes.c_int64),
                 ("rows", c_int), ("cols", c_int), ("raw_ld", c_int), ("raw_col0", c_int),
-                ("dst_ld", c_int), ("kind", c_int)]
+                ("dst_ld", c_int), ("kind", c_int),
+                ("g_off", ctypes.c_int64), ("g_ld", c_int), ("g_kind", c_int)]
 
 
 class DvaeError(RuntimeError):
@@ -57,6 +58,8 @@ SIGNATURES = {
     "dvae_sched_export": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dvae_enc_param_floats": (c_size_t, [_P(DvaeDims)]),
     "dvae_dec_param_floats": (c_size_t, [_P(DvaeDims)]),
+    "dvae_enc_grad_floats": (c_size_t, [_P(DvaeDims)]),
+    "dvae_dec_grad_floats": (c_size_t, [_P(DvaeDims)]),
     "dvae_enc_param_count": (c_int, [_P(DvaeDims)]),
     "dvae_dec_param_count": (c_int, [_P(DvaeDims)]),
     "dvae_enc_pack_table": (c_int, [_P(DvaeDims), c_void_p, c_void_p, c_void_p, c_int]),

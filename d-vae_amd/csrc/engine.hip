@@ -19,14 +19,12 @@ struct Carver {
 constexpr size_t GEMM_WS_BYTES = (size_t)96 << 20;
 
 size_t part_floats_for(const dvae_dims& d) {
-  size_t m = (size_t)(d.C + 2) * 3 * d.HP * 512;
-  m = std::max(m, (size_t)std::max(d.npos, 1) * 2 * d.HP * 128);
-  m = std::max(m, (size_t)(d.EHP + 4) * 2048);
+  size_t m = (size_t)(d.EHP + 4) * 2048;
   m = std::max(m, (size_t)d.EHP * 512);
   return m;
 }
 
-void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP) {
+void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP, int PP) {
   s.prefix = prefix;
   s.RH = prefix ? R + E : R;
   const size_t rh = (size_t)std::max(s.RH, 1), r = (size_t)std::max(R, 1);
@@ -36,6 +34,8 @@ void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP) {
   s.DH = c.f(rh * HP);
   s.GMP = c.f(r * 2 * HP);
   s.GM = c.f(r * HP);
+  s.XP = c.f(rh * 32);
+  s.PX = c.f(r * PP);
   if (prefix) {
     s.HV = c.f(rh * HP);
     s.Hn = c.f(r * HP);
@@ -58,13 +58,13 @@ struct EncWs {
 EncWs enc_ws(const dvae_dims& d, int R, int E, void* base) {
   EncWs w;
   Carver c{(char*)base, 0};
-  carve_sweep(c, w.f, 0, R, E, d.HP);
+  carve_sweep(c, w.f, 0, R, E, d.HP, pos_cols(d));
   const size_t B = d.B;
   w.ML = c.f(B * 2 * d.ZP);
   w.DML = c.f(B * 2 * d.ZP);
   w.DHVF = c.f(B * d.HP);
   if (d.bidir) {
-    carve_sweep(c, w.r, 0, R, E, d.HP);
+    carve_sweep(c, w.r, 0, R, E, d.HP, pos_cols(d));
     w.HVC = c.f((size_t)(d.N + 1) * B * d.HP);
     w.CAT = c.f((size_t)d.N * B * 2 * d.HP);
     w.DHVC = c.f((size_t)(d.N + 1) * B * d.HP);
@@ -94,7 +94,7 @@ struct DecWs {
 DecWs dec_ws(const dvae_dims& d, int R, int E, void* base) {
   DecWs w;
   Carver c{(char*)base, 0};
-  carve_sweep(c, w.s, 1, R, E, d.HP);
+  carve_sweep(c, w.s, 1, R, E, d.HP, pos_cols(d));
   const size_t B = d.B, r = std::max(R, 1), rh = std::max(R + E, 1);
   w.ZPAD = c.f(B * d.ZP);
   w.H0 = c.f(B * d.HP);
@@ -239,32 +239,27 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   return DVAE_OK;
 }
 
-// weight gradients of one sweep, reduced over all rows after the sweep
+// weight gradients of one sweep, reduced over all rows after the sweep.
+// Ggru -> dWhh [3HP][HP]; Xgru / Xgm -> the gradient-only regions of layout.h
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                float* Ggru, float* Ggm, float* part, size_t part_floats, const G& g) {
-  const int HP = d.HP;
+                float* Ggru, float* Ggm, float* Xgru, float* Xgm, const G& g) {
+  const int HP = d.HP, PP = pos_cols(d);
   hipStream_t st = g.st;
+  const int RH = lv.R > 0 ? b.RH : 0;
   // dWhh = dgh^T . h_in
-  DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, lv.R > 0 ? b.RH : 0));
-  if (lv.R > 0) {
-    DVAE_TRY(k_gru_wgrad(S, b, x, d.N, d.C, HP, Ggru + (size_t)3 * HP * HP, part, part_floats, st));
-  } else {
-    DVAE_CHECK_HIP(hipMemsetAsync(Ggru + (size_t)3 * HP * HP, 0, (size_t)(d.C + 2) * 3 * HP * 4, st));
-  }
+  DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, RH));
+  // dW_ih, db_ih, db_hh = (dgh | dn_pre)^T . (x | 1)
+  DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
+  DVAE_TRY(g.tn(b.GH, 3 * HP, b.XP, 32, Xgru, 32, 3 * HP, 32, RH));
+  DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xgru + (size_t)3 * HP * 32, 32, HP, 32, RH));
   if (d.mod == 0) {
     const int Rg = lv.nlev > 0 ? lv.ls[lv.nlev - 1] : 0;   // nodes that have a gate/map output
     DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
-    if (Rg > 0) {
-      DVAE_TRY(k_gm_wgrad_pos(S, Rg, b, d.npos, HP, Ggm + (size_t)2 * HP * HP, part, part_floats, st));
-    } else {
-      DVAE_CHECK_HIP(hipMemsetAsync(Ggm + (size_t)2 * HP * HP, 0, (size_t)d.npos * 2 * HP * 4, st));
-    }
+    DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
+    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, PP, Xgm, PP, 2 * HP, PP, Rg));
   } else {
-    if (lv.R > 0) {
-      DVAE_TRY(k_gm_wgrad_bn(S, lv.R, b, x, d.N, d.C, HP, Ggm, part, part_floats, st));
-    } else {
-      DVAE_CHECK_HIP(hipMemsetAsync(Ggm, 0, (size_t)(d.C + 1) * 2 * HP * 4, st));
-    }
+    DVAE_TRY(k_build_xp(S, 0, lv.R, x, d.N, d.C, b.PX, st));
+    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, 32, Xgm, 32, 2 * HP, 32, lv.R));
   }
   return DVAE_OK;
 }
@@ -370,12 +365,12 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     DVAE_TRY(g.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
     DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, w.part, w.part_floats, st));
     DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g));
-    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, w.part, w.part_floats, g));
+    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b, g));
   } else {
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
   DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g));
-  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, w.part, w.part_floats, g));
+  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, g));
   return DVAE_OK;
 }
 
@@ -473,7 +468,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
-  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, w.part, w.part_floats, g));
+  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, g));
 
   // ---- lin1 ----
   DVAE_TRY(g.tn(w.DH0, HP, w.ZPAD, d.ZP, Gp + L.Wl1, d.ZP, HP, d.ZP, B));

@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   using TA = Tile<AKM, BM>;
   using TB = Tile<BKM, BN>;
+  // one LDS stage (two barriers per k-tile): a second stage measured 5-34 % slower
+  // on this chip because it drops residency from three workgroups per CU to two
   __shared__ __attribute__((aligned(16))) float lds[TA::LDS_FLOATS + TB::LDS_FLOATS];
   float* As = lds;
   float* Bs = lds + TA::LDS_FLOATS;
@@ -308,16 +310,24 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   else DVAE_REQUIRE((d.M & 3) == 0, "gemm: M must be a multiple of 4 for a k-major A");
   if (!d.b_kmajor) DVAE_REQUIRE((d.K & 3) == 0, "gemm: K must be a multiple of 4 for an n-major B");
   else DVAE_REQUIRE((d.N & 3) == 0, "gemm: N must be a multiple of 4 for a k-major B");
+  // tile choice: narrow outputs take 128x32; otherwise the shape that needs the
+  // fewest "rounds" of 256 CUs (fp32 MFMA time is proportional to tile area)
   const bool narrow = d.N <= 32;
-  if (!d.a_kmajor && !d.b_kmajor)
-    return narrow ? launch<0, 0, 128, 32, 4, 1>(d, ws, ws_bytes, stream)
-                  : launch<0, 0, 128, 128, 2, 2>(d, ws, ws_bytes, stream);
-  if (!d.a_kmajor && d.b_kmajor)
-    return narrow ? launch<0, 1, 128, 32, 4, 1>(d, ws, ws_bytes, stream)
-                  : launch<0, 1, 128, 128, 2, 2>(d, ws, ws_bytes, stream);
-  if (d.a_kmajor && d.b_kmajor)
-    return narrow ? launch<1, 1, 128, 32, 4, 1>(d, ws, ws_bytes, stream)
-                  : launch<1, 1, 128, 128, 2, 2>(d, ws, ws_bytes, stream);
+  bool half = false;
+  if (!narrow) {
+    const long long t128 = (long long)cdiv(d.M, 128) * cdiv(d.N, 128);
+    const long long t64 = (long long)cdiv(d.M, 64) * cdiv(d.N, 128);
+    const long long c128 = ((t128 + 255) / 256) * 2, c64 = (t64 + 255) / 256;
+    half = c64 < c128 && t128 < 2048 && !(d.K >= 2048 && t128 < 256 && ws);   // split-K fills the chip instead
+  }
+#define GEMM_PICK(AK, BKK)                                                     \
+  return narrow ? launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream)      \
+         : half ? launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream)      \
+                : launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream)
+  if (!d.a_kmajor && !d.b_kmajor) { GEMM_PICK(0, 0); }
+  if (!d.a_kmajor && d.b_kmajor) { GEMM_PICK(0, 1); }
+  if (d.a_kmajor && d.b_kmajor) { GEMM_PICK(1, 1); }
+#undef GEMM_PICK
   dvae_set_error("gemm: layout a_kmajor=1,b_kmajor=0 is not used by this library");
   return DVAE_ERR_ARG;
 }

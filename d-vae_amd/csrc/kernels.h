@@ -34,6 +34,8 @@ struct SweepBufs {
   float* GM;        // [R][HP]   g*m
   float* DH;        // [RH][HP]  dL/dHV -> dL/dAGG after gru_bwd
   float* DHn;       // [R][HP]   prefix only: extra gradient of the final states
+  float* XP;        // [RH][32]  node encoding | 1 of every row (weight-gradient GEMMs)
+  float* PX;        // [R][PP]   None: position one-hot | 1; bn: node encoding | 1 per node
 };
 
 int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st);
@@ -45,15 +47,9 @@ int k_gm_bn_fwd(const SchedDir& S, int R, const SweepBufs& b, const float* x, in
 // with_gm_grad=0 (mod bn): only gathers dGM into GMP[:, :HP] scaled for the weight grads
 int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st);
-// out = dWihT | dbih | dbhh (contiguous, (C+2)*3HP floats), reduced over all RH rows
-int k_gru_wgrad(const SchedDir& S, const SweepBufs& b, const float* x, int N, int C, int HP, float* out,
-                float* part, size_t part_floats, hipStream_t st);
-// mod None: out = dposb [npos][2HP]
-int k_gm_wgrad_pos(const SchedDir& S, int R, const SweepBufs& b, int npos, int HP, float* out, float* part,
-                   size_t part_floats, hipStream_t st);
-// mod bn: out = dWgmT [C][2HP] | dbgm [2HP]
-int k_gm_wgrad_bn(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C, int HP,
-                  float* out, float* part, size_t part_floats, hipStream_t st);
+// one-hot side tables for the skinny weight gradients (see layout.h)
+int k_build_xp(const SchedDir& S, int prefix, int rows, const float* x, int N, int C, float* XP, hipStream_t st);
+int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_t st);
 // out[w] = sum_rows X[row][w]   (W % 4 == 0)
 int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
              hipStream_t st);

@@ -216,108 +216,53 @@ __global__ void gru_bwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __
 // ---------------------------------------------------------------------------
 // deterministic column reductions for the skinny weight gradients
 // ---------------------------------------------------------------------------
-// out[k] = sum_c part[c*stride + k]
-__global__ void reduce_parts_kernel(const float* __restrict__ part, int nparts, size_t stride,
-                                    float* __restrict__ out, size_t len) {
-  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < len; k += (size_t)gridDim.x * blockDim.x) {
+// out[k] = sum_c part[c*stride + k]; 64 columns x 4 interleaved chunk groups per
+// block, combined in a fixed order
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts,
+                                                           size_t stride, float* __restrict__ out, size_t len) {
+  __shared__ float sh[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (size_t base = (size_t)blockIdx.x * 64; base < len; base += (size_t)gridDim.x * 64) {
+    const size_t k = base + col;
     float s = 0.f;
-    for (int c = 0; c < nparts; ++c) s += part[c * stride + k];
-    out[k] = s;
+    if (k < len)
+      for (int c = grp; c < nparts; c += 4) s += part[c * stride + k];
+    sh[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && k < len) out[k] = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
+    __syncthreads();
   }
 }
 
 int reduce_parts(const float* part, int nparts, size_t stride, float* out, size_t len, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_parts_kernel, grid_for((long long)len, 2048), dim3(256), 0, st, part, nparts,
-                     stride, out, len);
+  const int grid = (int)std::min<size_t>((len + 63) / 64, 4096);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(grid), dim3(256), 0, st, part, nparts, stride, out, len);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
 
-// thread = one hidden column j; rows [chunk*rpc, ...).  Partial layout per chunk:
-// [C][3HP] dWihT | [3HP] dbih | [3HP] dbhh
-__global__ __launch_bounds__(64) void gru_wgrad_kernel(SchedDir S, int prefix, int RH, int rpc,
-                                                       const float* __restrict__ GH,
-                                                       const float* __restrict__ GHN,
-                                                       const float* __restrict__ x, int N, int C, int HP,
-                                                       float* __restrict__ part) {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const int chunk = blockIdx.y;
-  const int p0 = chunk * rpc, p1 = min(RH, p0 + rpc);
-  float acc[3][DVAE_MAX_C];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int c = 0; c < DVAE_MAX_C; ++c) acc[g][c] = 0.f;
-  float bi[3] = {0.f, 0.f, 0.f};
-  float bhn = 0.f;
-  for (int p = p0; p < p1; ++p) {
+// one-hot side tables for the skinny weight gradients (TN GEMMs):
+//   XP [rows][32]: node encoding of the row's node in cols [0,C), 1 in col C
+//   PX [R][PP]   : one-hot of the node's position in cols [0,npos), 1 in col npos
+__global__ void build_xp_kernel(SchedDir S, int prefix, int rows, const float* __restrict__ x, int N, int C,
+                                float* __restrict__ XP) {
+  const long long total = (long long)rows * 32;
+  ITEM_LOOP(total) {
+    const int p = (int)(it >> 5), c = (int)(it & 31);
     const int r = prefix ? S.prow_node[p] : p;
-    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
-    const float* gh = GH + (size_t)p * 3 * HP;
-    const float d0 = gh[j], d1 = gh[HP + j], dhn = gh[2 * HP + j];
-    const float d2 = GHN[(size_t)p * HP + j];
-    bi[0] += d0; bi[1] += d1; bi[2] += d2; bhn += dhn;
-#pragma unroll
-    for (int c = 0; c < DVAE_MAX_C; ++c) {
-      if (c < C) {
-        const float xv = xr[c];
-        acc[0][c] = fmaf(xv, d0, acc[0][c]);
-        acc[1][c] = fmaf(xv, d1, acc[1][c]);
-        acc[2][c] = fmaf(xv, d2, acc[2][c]);
-      }
-    }
+    float v = 0.f;
+    if (c < C) v = x[((size_t)S.row_graph[r] * N + S.row_node[r]) * C + c];
+    else if (c == C) v = 1.f;
+    XP[it] = v;
   }
-  float* out = part + (size_t)chunk * (C + 2) * 3 * HP;
-#pragma unroll
-  for (int c = 0; c < DVAE_MAX_C; ++c)
-    if (c < C) {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) out[(size_t)c * 3 * HP + g * HP + j] = acc[g][c];
-    }
-  float* ob = out + (size_t)C * 3 * HP;
-  ob[j] = bi[0]; ob[HP + j] = bi[1]; ob[2 * HP + j] = bi[2];
-  ob[3 * HP + j] = bi[0]; ob[4 * HP + j] = bi[1]; ob[5 * HP + j] = bhn;
 }
 
-// position-keyed column sums of DGMP -> dposb[npos][2HP]; LDS accumulators [npos][64]
-__global__ __launch_bounds__(64) void gm_wgrad_pos_kernel(SchedDir S, int R, int rpc,
-                                                          const float* __restrict__ DGMP, int npos, int HP,
-                                                          float* __restrict__ part) {
-  __shared__ float acc[DVAE_MAX_N][64];
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  const int chunk = blockIdx.y;
-  for (int i = 0; i < npos; ++i) acc[i][threadIdx.x] = 0.f;
-  const int r0 = chunk * rpc, r1 = min(R, r0 + rpc);
-  for (int r = r0; r < r1; ++r) acc[S.row_node[r]][threadIdx.x] += DGMP[(size_t)r * 2 * HP + col];
-  float* out = part + (size_t)chunk * npos * 2 * HP;
-  for (int i = 0; i < npos; ++i) out[(size_t)i * 2 * HP + col] = acc[i][threadIdx.x];
-}
-
-// mod bn: dWgmT[c][2HP] = sum_rows x[c] * DGMP[row], dbgm = colsum
-__global__ __launch_bounds__(64) void gm_wgrad_bn_kernel(SchedDir S, int R, int rpc,
-                                                         const float* __restrict__ DGMP,
-                                                         const float* __restrict__ x, int N, int C, int HP,
-                                                         float* __restrict__ part) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  const int chunk = blockIdx.y;
-  float acc[DVAE_MAX_C];
-#pragma unroll
-  for (int c = 0; c < DVAE_MAX_C; ++c) acc[c] = 0.f;
-  float bs = 0.f;
-  const int r0 = chunk * rpc, r1 = min(R, r0 + rpc);
-  for (int r = r0; r < r1; ++r) {
-    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
-    const float d = DGMP[(size_t)r * 2 * HP + col];
-    bs += d;
-#pragma unroll
-    for (int c = 0; c < DVAE_MAX_C; ++c)
-      if (c < C) acc[c] = fmaf(xr[c], d, acc[c]);
+__global__ void build_px_kernel(SchedDir S, int R, int npos, int PP, float* __restrict__ PX) {
+  const long long total = (long long)R * PP;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / PP), c = (int)(it % PP);
+    PX[it] = (c == S.row_node[r] || c == npos) ? 1.f : 0.f;
   }
-  float* out = part + (size_t)chunk * (C + 1) * 2 * HP;
-#pragma unroll
-  for (int c = 0; c < DVAE_MAX_C; ++c)
-    if (c < C) out[(size_t)c * 2 * HP + col] = acc[c];
-  out[(size_t)C * 2 * HP + col] = bs;
 }
 
 __global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc,
@@ -776,40 +721,18 @@ int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hip
   return DVAE_OK;
 }
 
-int k_gru_wgrad(const SchedDir& S, const SweepBufs& b, const float* x, int N, int C, int HP, float* out,
-                float* part, size_t part_floats, hipStream_t st) {
-  const size_t per = (size_t)(C + 2) * 3 * HP;
-  int nch, rpc;
-  chunking(b.RH, per, part_floats, 512, &nch, &rpc);
-  DVAE_REQUIRE(part_floats >= per, "gru_wgrad: scratch too small");
-  hipLaunchKernelGGL(gru_wgrad_kernel, dim3(HP / 64, nch), dim3(64), 0, st, S, b.prefix, b.RH, rpc, b.GH, b.GHN,
-                     x, N, C, HP, part);
+int k_build_xp(const SchedDir& S, int prefix, int rows, const float* x, int N, int C, float* XP, hipStream_t st) {
+  if (rows <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(build_xp_kernel, grid_for((long long)rows * 32), dim3(256), 0, st, S, prefix, rows, x, N, C, XP);
   DVAE_LAUNCH_CHECK();
-  return reduce_parts(part, nch, per, out, per, st);
+  return DVAE_OK;
 }
 
-int k_gm_wgrad_pos(const SchedDir& S, int R, const SweepBufs& b, int npos, int HP, float* out, float* part,
-                   size_t part_floats, hipStream_t st) {
-  const size_t per = (size_t)npos * 2 * HP;
-  int nch, rpc;
-  chunking(R, per, part_floats, 128, &nch, &rpc);
-  DVAE_REQUIRE(part_floats >= per, "gm_wgrad_pos: scratch too small");
-  hipLaunchKernelGGL(gm_wgrad_pos_kernel, dim3(2 * HP / 64, nch), dim3(64), 0, st, S, R, rpc, b.GMP, npos, HP,
-                     part);
+int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(build_px_kernel, grid_for((long long)R * PP), dim3(256), 0, st, S, R, npos, PP, PX);
   DVAE_LAUNCH_CHECK();
-  return reduce_parts(part, nch, per, out, per, st);
-}
-
-int k_gm_wgrad_bn(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C, int HP,
-                  float* out, float* part, size_t part_floats, hipStream_t st) {
-  const size_t per = (size_t)(C + 1) * 2 * HP;
-  int nch, rpc;
-  chunking(R, per, part_floats, 512, &nch, &rpc);
-  DVAE_REQUIRE(part_floats >= per, "gm_wgrad_bn: scratch too small");
-  hipLaunchKernelGGL(gm_wgrad_bn_kernel, dim3(2 * HP / 64, nch), dim3(64), 0, st, S, R, rpc, b.GMP, x, N, C, HP,
-                     part);
-  DVAE_LAUNCH_CHECK();
-  return reduce_parts(part, nch, per, out, per, st);
+  return DVAE_OK;
 }
 
 int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,

@@ -7,6 +7,8 @@ struct EncLayout {
   size_t gru_f, gm_f, Wml, bml;          // forward sweep, heads (lin11 rows [0,Z), lin12 rows [ZP,ZP+Z))
   size_t gru_b, gm_b, W01, b01;          // bidirectional only
   size_t total;
+  // gradient-only regions (packed gradient buffer = [0,total) + these)
+  size_t xg_gru_f, xg_gm_f, xg_gru_b, xg_gm_b, gtotal;
 };
 struct DecLayout {
   size_t Wl1, bl1;                        // lin1 [HP][ZP]
@@ -14,7 +16,17 @@ struct DecLayout {
   size_t Wv1, bv1, Wv2, bv2;              // add_vertex [VHP][HP], [CP][VHP]
   size_t W1a, W1b, W1c, b1, w2, b2;       // add_edge.0 split by input block, add_edge.2
   size_t total;
+  size_t xg_gru, xg_gm, gtotal;           // gradient-only regions
 };
+
+// Skinny weight gradients come out of TN GEMMs against a 32-column one-hot table
+// (node type | 1) or a PP-column one (node position | 1):
+//   GRU : [3HP][32] = dgh^T.XP (cols <C: dW_ih r,z gates; col C: db_ih r,z and db_hh)
+//         [HP][32]  = dn_pre^T.XP (dW_ih n gate, db_ih n gate)
+//   gate/map: [2HP][PP] (None) or [2HP][32] (bn)
+static inline int pos_cols(const dvae_dims& d) { return d.mod == 0 ? (d.npos + 1 + 31) / 32 * 32 : 32; }
+static inline size_t xg_gru_floats(const dvae_dims& d) { return (size_t)4 * d.HP * 32; }
+static inline size_t xg_gm_floats(const dvae_dims& d) { return (size_t)2 * d.HP * pos_cols(d); }
 
 static inline EncLayout enc_layout(const dvae_dims& d) {
   EncLayout L;
@@ -32,6 +44,14 @@ static inline EncLayout enc_layout(const dvae_dims& d) {
     L.b01 = take((size_t)d.HP);
   }
   L.total = o;
+  L.xg_gru_f = take(xg_gru_floats(d));
+  L.xg_gm_f = take(xg_gm_floats(d));
+  L.xg_gru_b = L.xg_gm_b = 0;
+  if (d.bidir) {
+    L.xg_gru_b = take(xg_gru_floats(d));
+    L.xg_gm_b = take(xg_gm_floats(d));
+  }
+  L.gtotal = o;
   return L;
 }
 
@@ -54,5 +74,8 @@ static inline DecLayout dec_layout(const dvae_dims& d) {
   L.w2 = take((size_t)d.EHP);
   L.b2 = take(64);
   L.total = o;
+  L.xg_gru = take(xg_gru_floats(d));
+  L.xg_gm = take(xg_gm_floats(d));
+  L.gtotal = o;
   return L;
 }

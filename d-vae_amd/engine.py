@@ -113,10 +113,10 @@ class ParamPack:
             o += p.numel()
         self.offsets, self.total = offs, o
         goff = np.array(offs, dtype=np.int64)
-        host = (_lib.PackEntry * 128)()
+        host = (_lib.PackEntry * 256)()
         fn = lib.dvae_enc_pack_table if self.kind == "enc" else lib.dvae_dec_pack_table
         n = fn(ctypes.byref(dims), ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(goff.ctypes.data),
-               ctypes.cast(host, ctypes.c_void_p), 128)
+               ctypes.cast(host, ctypes.c_void_p), 256)
         if n < 0:
             check(n)
         self.n = n
@@ -125,6 +125,8 @@ class ParamPack:
         self.table = torch.from_numpy(blob).to(dev)
         nfl = (lib.dvae_enc_param_floats if self.kind == "enc" else lib.dvae_dec_param_floats)(ctypes.byref(dims))
         self.nfloats = int(nfl)
+        gfl = (lib.dvae_enc_grad_floats if self.kind == "enc" else lib.dvae_dec_grad_floats)(ctypes.byref(dims))
+        self.gfloats = int(gfl)
         self.P = torch.zeros(self.nfloats, dtype=torch.float32, device=dev)
 
     def pack(self, dims, params):
@@ -139,7 +141,7 @@ class ParamPack:
         return self.P
 
     def new_packed_grad(self):
-        return torch.zeros(self.nfloats, dtype=torch.float32, device=self.P.device)
+        return torch.zeros(self.gfloats, dtype=torch.float32, device=self.P.device)
 
     def unpack(self, G, flat=None):
         """packed gradient buffer -> flat reference-shaped gradients (views returned)."""

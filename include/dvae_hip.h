@@ -120,11 +120,19 @@ typedef struct dvae_pack_entry {
   int rows, cols;    /* block extent in the raw tensor                      */
   int raw_ld, raw_col0;
   int dst_ld;
-  int kind;          /* 0 copy, 1 transposed, 2 transposed + aux[r]         */
+  int kind;          /* packed side: 0 copy, 1 transposed, 2 transposed +
+                        aux[r], -1 = entry is gradient-only                 */
+  int64_t g_off;     /* gradient side: float offset in the packed GRADIENT
+                        buffer (its layout differs where a weight gradient
+                        comes out of a [features][32] GEMM)                 */
+  int g_ld;
+  int g_kind;        /* 0 copy, 1 transposed, -1 = no gradient from here    */
 } dvae_pack_entry;
 
 size_t dvae_enc_param_floats(const dvae_dims* d);
 size_t dvae_dec_param_floats(const dvae_dims* d);
+size_t dvae_enc_grad_floats(const dvae_dims* d);   /* packed gradient buffer sizes */
+size_t dvae_dec_grad_floats(const dvae_dims* d);
 int dvae_enc_param_count(const dvae_dims* d);   /* raw tensors expected */
 int dvae_dec_param_count(const dvae_dims* d);
 int dvae_enc_pack_table(const dvae_dims* d, const uint64_t* raw_host, const int64_t* grad_off_host,
