@@ -26,6 +26,7 @@ size_t part_floats_for(const dvae_dims& d) {
 
 void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP, int PP) {
   s.prefix = prefix;
+  s.R = R;
   s.RH = prefix ? R + E : R;
   const size_t rh = (size_t)std::max(s.RH, 1), r = (size_t)std::max(R, 1);
   s.AGG = c.f(rh * HP);
@@ -135,15 +136,17 @@ struct G {
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dW[M][N] = dY[K][M]^T X[K][N]   (K = rows)
-  int tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, int K) const {
+  int tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, int K,
+         int acc = 0) const {
     if (K <= 0) {
+      if (acc) return DVAE_OK;
       if (hipMemset2DAsync(dW, (size_t)ldw * 4, 0, (size_t)N * 4, M, st) != hipSuccess) {
         dvae_set_error("memset2d failed");
         return DVAE_ERR_HIP;
       }
       return DVAE_OK;
     }
-    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, 0};
+    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
 };
@@ -176,31 +179,48 @@ struct SweepW {
   GruW gru; const float* gm;   // gm: Wgm|posb (None) or WgmT|bgm (bn)
 };
 
-// level sweep forward (dvae_model.py:63-87 / :93-116 / the final-state part of :196-249)
+// level sweep forward (dvae_model.py:63-87 / :93-116 / the final-state part of :196-249).
+// Row classes of a prefix (decoder) sweep, see sched.h: node rows [ls[L], ls[L+1]) carry
+// the k = 0 states (h_in = 0, or h0 for node 0 -> only level 0 needs the hidden GEMM);
+// edge rows R + [es[L], es[L+1]) carry the running predecessor sums.
 int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
               const float* x, const float* h0, const G& g) {
-  const int HP = d.HP;
+  const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
-  if (lv.R <= 0) return DVAE_OK;
+  if (R <= 0) return DVAE_OK;
+  const int z1 = lv.nlev > 0 ? lv.ls[1] : R;   // end of level 0
+  auto hidden_gemm = [&](int p0, int p1) {
+    return g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0, 3 * HP, HP);
+  };
   if (d.mod == 1) {
-    DVAE_TRY(k_gm_bn_fwd(S, lv.R, b, x, d.N, d.C, w.gm, w.gm + (size_t)d.C * 2 * HP, HP, st));
-    DVAE_TRY(k_agg_fwd(S, 0, lv.R, b, h0, HP, st));
-    DVAE_TRY(g.nt(b.AGG, HP, w.gru.Whh, HP, b.GH, 3 * HP, b.RH, 3 * HP, HP));
-    DVAE_TRY(k_gru_fwd(S, 0, b.RH, b, x, d.N, d.C, w.gru, HP, st));
+    // gate/map depends on node types only: no inter-node dependency, one "level"
+    DVAE_TRY(k_gm_bn_fwd(S, R, b, x, d.N, d.C, w.gm, w.gm + (size_t)d.C * 2 * HP, HP, st));
+    DVAE_TRY(k_agg_fwd(S, 0, R, b, h0, HP, st));
+    if (!b.prefix) {
+      DVAE_TRY(hidden_gemm(0, R));
+      DVAE_TRY(k_gru_fwd(S, 0, R, 0, b, x, d.N, d.C, w.gru, HP, st));
+    } else {
+      DVAE_TRY(hidden_gemm(0, z1));
+      DVAE_TRY(hidden_gemm(R, b.RH));
+      DVAE_TRY(k_gru_fwd(S, 0, z1, 0, b, x, d.N, d.C, w.gru, HP, st));
+      DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
+      DVAE_TRY(k_gru_fwd(S, R, b.RH, 0, b, x, d.N, d.C, w.gru, HP, st));
+    }
     return DVAE_OK;
   }
+  // rows whose h_in is 0 depend on nothing but the node type: all levels in one launch
+  if (b.prefix) DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
   for (int L = 0; L < lv.nlev; ++L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
-    const int p0 = b.prefix ? ns + lv.es[L] : ns, p1 = b.prefix ? ne + lv.es[L + 1] : ne;
     DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st));
-    if (L == 0 && !h0) {
-      // no predecessors and no seed: h_in = 0, the hidden GEMM vanishes
-      DVAE_CHECK_HIP(hipMemsetAsync(b.GH + (size_t)p0 * 3 * HP, 0, (size_t)(p1 - p0) * 3 * HP * 4, st));
+    if (L == 0) {
+      if (h0) DVAE_TRY(hidden_gemm(ns, ne));
+      DVAE_TRY(k_gru_fwd(S, ns, ne, h0 ? 0 : 1, b, x, d.N, d.C, w.gru, HP, st));
     } else {
-      DVAE_TRY(g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0,
-                    3 * HP, HP));
+      const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
+      DVAE_TRY(hidden_gemm(p0, p1));
+      DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));
     }
-    DVAE_TRY(k_gru_fwd(S, p0, p1, b, x, d.N, d.C, w.gru, HP, st));
     if (L + 1 < lv.nlev) {   // nodes of the last level have no successors
       DVAE_TRY(g.nt(b.Hn + (size_t)ns * HP, HP, w.gm, HP, b.GMP + (size_t)ns * 2 * HP, 2 * HP, ne - ns, 2 * HP,
                     HP));
@@ -213,41 +233,63 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
 // reverse-level sweep: DH holds dL/dHV on entry, dL/dAGG on exit
 int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
               bool seeded, const G& g) {
-  const int HP = d.HP;
+  const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
-  if (lv.R <= 0) return DVAE_OK;
+  if (R <= 0) return DVAE_OK;
+  const int z1 = lv.nlev > 0 ? lv.ls[1] : R;
+  auto dagg_gemm = [&](int p0, int p1) {   // dAGG += dgh . Whh
+    return g.nn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DH + (size_t)p0 * HP, HP, p1 - p0, HP, 3 * HP, 1);
+  };
   if (d.mod == 1) {
     DVAE_TRY(k_gru_bwd(S, 0, b.RH, b, HP, st));
-    DVAE_TRY(g.nn(b.GH, 3 * HP, w.gru.Whh, HP, b.DH, HP, b.RH, HP, 3 * HP, 1));
-    DVAE_TRY(k_dgm_bwd(S, 0, lv.R, b, HP, st));
+    if (!b.prefix) {
+      DVAE_TRY(dagg_gemm(0, R));
+    } else {
+      if (seeded) DVAE_TRY(dagg_gemm(0, z1));
+      DVAE_TRY(dagg_gemm(R, b.RH));
+    }
+    DVAE_TRY(k_dgm_bwd(S, 0, R, b, HP, st));
     return DVAE_OK;
   }
   float* dtarget = b.prefix ? b.DHn : b.DH;
   for (int L = lv.nlev - 1; L >= 0; --L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
-    const int p0 = b.prefix ? ns + lv.es[L] : ns, p1 = b.prefix ? ne + lv.es[L + 1] : ne;
     if (L + 1 < lv.nlev) {
       DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
       DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
                     2 * HP, 1));
     }
-    DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
-    if (L > 0 || seeded)
-      DVAE_TRY(g.nn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DH + (size_t)p0 * HP, HP, p1 - p0, HP,
-                    3 * HP, 1));
+    if (L == 0) {
+      DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st));
+      if (seeded) DVAE_TRY(dagg_gemm(ns, ne));      // only node 0's h_in = h0 needs it
+    } else {
+      const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
+      DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
+      DVAE_TRY(dagg_gemm(p0, p1));
+    }
   }
+  // k = 0 rows of the later levels feed nothing backwards except the weight gradients
+  if (b.prefix) DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
   return DVAE_OK;
 }
 
 // weight gradients of one sweep, reduced over all rows after the sweep.
 // Ggru -> dWhh [3HP][HP]; Xgru / Xgm -> the gradient-only regions of layout.h
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                float* Ggru, float* Ggm, float* Xgru, float* Xgm, const G& g) {
-  const int HP = d.HP, PP = pos_cols(d);
+                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g) {
+  const int HP = d.HP, PP = pos_cols(d), R = lv.R;
   hipStream_t st = g.st;
-  const int RH = lv.R > 0 ? b.RH : 0;
-  // dWhh = dgh^T . h_in
-  DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, RH));
+  const int RH = R > 0 ? b.RH : 0;
+  const int z1 = (R > 0 && lv.nlev > 0) ? lv.ls[1] : 0;
+  // dWhh = dgh^T . h_in over the rows whose h_in is not identically zero
+  if (!b.prefix) {
+    const int skip = d.mod == 0 ? z1 : 0;      // level 0 of a node sweep has h_in = 0
+    DVAE_TRY(g.tn(b.GH + (size_t)skip * 3 * HP, 3 * HP, b.AGG + (size_t)skip * HP, HP, Ggru, HP, 3 * HP, HP,
+                  R - skip));
+  } else {
+    DVAE_TRY(g.tn(b.GH + (size_t)R * 3 * HP, 3 * HP, b.AGG + (size_t)R * HP, HP, Ggru, HP, 3 * HP, HP, RH - R));
+    if (seeded && z1 > 0) DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, z1, 1));
+  }
   // dW_ih, db_ih, db_hh = (dgh | dn_pre)^T . (x | 1)
   DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
   DVAE_TRY(g.tn(b.GH, 3 * HP, b.XP, 32, Xgru, 32, 3 * HP, 32, RH));
@@ -258,8 +300,8 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
     DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
     DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, PP, Xgm, PP, 2 * HP, PP, Rg));
   } else {
-    DVAE_TRY(k_build_xp(S, 0, lv.R, x, d.N, d.C, b.PX, st));
-    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, 32, Xgm, 32, 2 * HP, 32, lv.R));
+    DVAE_TRY(k_build_xp(S, 0, R, x, d.N, d.C, b.PX, st));
+    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, 32, Xgm, 32, 2 * HP, 32, R));
   }
   return DVAE_OK;
 }
@@ -365,12 +407,12 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     DVAE_TRY(g.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
     DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, w.part, w.part_floats, st));
     DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g));
-    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b, g));
+    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b, false, g));
   } else {
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
   DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g));
-  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, g));
+  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, false, g));
   return DVAE_OK;
 }
 
@@ -439,7 +481,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E, EHP = d.EHP;
 
   // ---- add_edge ----
-  DVAE_TRY(k_pair_bwd_a(sv, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, w.part, w.part_floats, EHP, st));
+  DVAE_TRY(k_pair_bwd_a(sv, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, w.part, w.part_floats, EHP, st));
   DVAE_TRY(k_pair_bwd_b(sv, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
   DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
   DVAE_TRY(g.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
@@ -468,7 +510,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
-  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, g));
+  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, g));
 
   // ---- lin1 ----
   DVAE_TRY(g.tn(w.DH0, HP, w.ZPAD, d.ZP, Gp + L.Wl1, d.ZP, HP, d.ZP, B));

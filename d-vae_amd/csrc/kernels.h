@@ -24,6 +24,7 @@ static inline size_t gm_floats(int HP, int C, int npos, int mod) {
 // One level sweep's tables (encoder forward, encoder reverse, decoder).
 struct SweepBufs {
   int prefix;       // 1: decoder (one row per (node, prefix length k)); 0: one row per node
+  int R;            // node rows
   int RH;           // rows of the h-tables: R (+E when prefix)
   float* AGG;       // [RH][HP]  h_in of every row
   float* GH;        // [RH][3HP] hidden GEMM -> (r,z,n) after gru_fwd -> dgh after gru_bwd
@@ -39,7 +40,7 @@ struct SweepBufs {
 };
 
 int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st);
-int k_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, const float* x, int N, int C,
               const GruW& w, int HP, hipStream_t st);
 int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st);
 int k_gm_bn_fwd(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C,
@@ -79,7 +80,7 @@ int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int
 int k_pair_fwd(const SchedView& sv, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
                const float* b2, float* edge_logits, int EHP, hipStream_t st);
 // DA [RH][EHP]; out = dw2 [EHP] | db2 [4]
-int k_pair_bwd_a(const SchedView& sv, int RH, const float* A, const float* Bq, const float* Cq,
+int k_pair_bwd_a(const SchedView& sv, int R, int RH, const float* A, const float* Bq, const float* Cq,
                  const float* w2, const float* d_edge, float* DA, float* out, float* part,
                  size_t part_floats, int EHP, hipStream_t st);
 int k_pair_bwd_b(const SchedView& sv, int R, const int* sizes, const float* A, const float* Bq,

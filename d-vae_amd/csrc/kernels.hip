@@ -37,7 +37,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // aggregation: h_in = sum of gated states of the predecessors (dvae_model.py:77-80)
 // prefix mode writes every running sum (decoder suffix states, :223-241).
 // ---------------------------------------------------------------------------
-__global__ void agg_fwd_kernel(SchedDir S, int ns, int ne, int prefix, const float* __restrict__ GM,
+__global__ void agg_fwd_kernel(SchedDir S, int R, int ns, int ne, int prefix, const float* __restrict__ GM,
                                float* __restrict__ AGG, const float* __restrict__ h0, int HP) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(ne - ns) * HP4;
@@ -49,12 +49,12 @@ __global__ void agg_fwd_kernel(SchedDir S, int ns, int ne, int prefix, const flo
       for (int t = 0; t < deg; ++t) acc = add4(acc, ld4(GM + (size_t)S.csr_idx[p + t] * HP + q * 4));
       st4(AGG + (size_t)r * HP + q * 4, acc);
     } else {
-      const size_t p0 = (size_t)p + r;
+      // row r itself holds the k = 0 state (h0 for node 0, else 0); edge rows the running sums
       if (h0 && S.row_node[r] == 0) acc = ld4(h0 + (size_t)S.row_graph[r] * HP + q * 4);
-      st4(AGG + p0 * HP + q * 4, acc);
+      st4(AGG + (size_t)r * HP + q * 4, acc);
       for (int t = 0; t < deg; ++t) {
         acc = add4(acc, ld4(GM + (size_t)S.csr_idx[p + t] * HP + q * 4));
-        st4(AGG + (p0 + t + 1) * HP + q * 4, acc);
+        st4(AGG + ((size_t)R + p + t) * HP + q * 4, acc);
       }
     }
   }
@@ -63,7 +63,7 @@ __global__ void agg_fwd_kernel(SchedDir S, int ns, int ne, int prefix, const flo
 // ---------------------------------------------------------------------------
 // GRUCell epilogue (gate order r,z,n; dvae_model.py:83,244).  GH holds agg.Whh^T.
 // ---------------------------------------------------------------------------
-__global__ void gru_fwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __restrict__ GH,
+__global__ void gru_fwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, int no_gh, float* __restrict__ GH,
                                const float* __restrict__ AGG, float* __restrict__ GHN,
                                float* __restrict__ HV, float* __restrict__ Hn,
                                const float* __restrict__ x, int N, int C, GruW w, int HP) {
@@ -86,10 +86,15 @@ __global__ void gru_fwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __
       }
     }
     float* gh = GH + (size_t)p * 3 * HP;
-    const float4 ghr = add4(ld4(gh + j), ld4(w.bhh + j));
-    const float4 ghz = add4(ld4(gh + HP + j), ld4(w.bhh + HP + j));
-    const float4 ghn = add4(ld4(gh + 2 * HP + j), ld4(w.bhh + 2 * HP + j));
-    const float4 a = ld4(AGG + (size_t)p * HP + j);
+    // no_gh: h_in = 0 for these rows, so the hidden product is just the bias
+    float4 ghr = ld4(w.bhh + j), ghz = ld4(w.bhh + HP + j), ghn = ld4(w.bhh + 2 * HP + j);
+    float4 a = zero4();
+    if (!no_gh) {
+      ghr = add4(ghr, ld4(gh + j));
+      ghz = add4(ghz, ld4(gh + HP + j));
+      ghn = add4(ghn, ld4(gh + 2 * HP + j));
+      a = ld4(AGG + (size_t)p * HP + j);
+    }
     float4 rr, zz, nn, hh;
 #define GRU_LANE(f)                                   \
     rr.f = sigm(gi[0].f + ghr.f);                     \
@@ -103,7 +108,7 @@ __global__ void gru_fwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __
     st4(gh + 2 * HP + j, nn);
     st4(GHN + (size_t)p * HP + j, ghn);
     st4(HV + (size_t)p * HP + j, hh);
-    if (prefix && p == S.csr_ptr[r + 1] + r) st4(Hn + (size_t)r * HP + j, hh);
+    if (prefix && p == final_prow(S, R, r)) st4(Hn + (size_t)r * HP + j, hh);
   }
 }
 
@@ -180,7 +185,7 @@ __global__ void dgm_bwd_kernel(SchedDir S, int ns, int ne, int prefix, const flo
 
 // GRUCell backward epilogue: GH (r,z,n) -> (dr_pre, dz_pre, dn_pre*r) = d(gh);
 // GHN -> dn_pre (so d(gi) = (GH_r, GH_z, GHN)); DH -> dh*z (direct path to h_in)
-__global__ void gru_bwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __restrict__ GH,
+__global__ void gru_bwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, float* __restrict__ GH,
                                float* __restrict__ GHN, const float* __restrict__ AGG,
                                float* __restrict__ DH, const float* __restrict__ DHn, int HP) {
   const int HP4 = HP >> 2;
@@ -190,7 +195,7 @@ __global__ void gru_bwd_kernel(SchedDir S, int p0, int p1, int prefix, float* __
     float4 dh = ld4(DH + (size_t)p * HP + j);
     if (prefix && DHn) {
       const int r = S.prow_node[p];
-      if (p == S.csr_ptr[r + 1] + r) dh = add4(dh, ld4(DHn + (size_t)r * HP + j));
+      if (p == final_prow(S, R, r)) dh = add4(dh, ld4(DHn + (size_t)r * HP + j));
     }
     float* gh = GH + (size_t)p * 3 * HP;
     const float4 rr = ld4(gh + j), zz = ld4(gh + HP + j), nn = ld4(gh + 2 * HP + j);
@@ -442,8 +447,7 @@ __global__ void add_dh0_kernel(SchedDir S, int B, int N, const float* __restrict
     const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
     const int r = S.node2row[b * N];
     if (r < 0) continue;
-    const size_t p = (size_t)S.csr_ptr[r] + r;
-    st4(dh0 + (size_t)b * HP + j, add4(ld4(dh0 + (size_t)b * HP + j), ld4(DAGG + p * HP + j)));
+    st4(dh0 + (size_t)b * HP + j, add4(ld4(dh0 + (size_t)b * HP + j), ld4(DAGG + (size_t)r * HP + j)));
   }
 }
 
@@ -505,7 +509,6 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, int R, cons
     if (i == 0) continue;
     const int b = S.row_graph[r];
     const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
-    const size_t p0 = (size_t)p + r;
     int t = 0, cur = -1;
     int next_pred = deg > 0 ? S.row_node[S.csr_idx[p]] : -1;
     float4 a[VPL], c[VPL];
@@ -518,7 +521,8 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, int R, cons
       }
       if (t != cur) {
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) a[v] = add4(ld4(A + (p0 + t) * EHP + (lane + 64 * v) * 4), c[v]);
+        for (int v = 0; v < VPL; ++v)
+          a[v] = add4(ld4(A + (size_t)prow_of(S, R, r, t) * EHP + (lane + 64 * v) * 4), c[v]);
         cur = t;
       }
       const size_t rj = S.node2row[b * N + j];
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, int R, cons
 
 // one wave per prefix row p = (i,k): pairs j in [u_{k+1}, u_k - 1]
 template <int VPL>
-__global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, int RH, const float* __restrict__ A,
+__global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, int R, int RH, const float* __restrict__ A,
                                                          const float* __restrict__ Bq,
                                                          const float* __restrict__ Cq,
                                                          const float* __restrict__ w2,
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, int RH, c
     const int r = S.prow_node[p];
     const int i = S.row_node[r], b = S.row_graph[r];
     const int e0 = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - e0;
-    const int k = p - (e0 + r);
+    const int k = p < R ? 0 : p - R - e0 + 1;
     const int hi = (k == 0 ? i : S.row_node[S.csr_idx[e0 + k - 1]]) - 1;
     const int lo = k < deg ? S.row_node[S.csr_idx[e0 + k]] : 0;
     float4 a[VPL], da[VPL];
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, int R, co
         else if (w == (j >> 5)) m &= ((j & 31) == 31) ? 0u : (~0u << ((j & 31) + 1));
         k += __popc(m);
       }
-      const size_t pr = (size_t)S.csr_ptr[ri] + ri + k;
+      const size_t pr = (size_t)prow_of(S, R, ri, k);
       const float ds = d_edge[((size_t)b * N + i) * N + j];
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
@@ -673,17 +677,17 @@ __global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, int R, co
 // ===========================================================================
 int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st) {
   if (ne <= ns) return DVAE_OK;
-  hipLaunchKernelGGL(agg_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, ns, ne,
+  hipLaunchKernelGGL(agg_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns, ne,
                      b.prefix, b.GM, b.AGG, h0, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
 
-int k_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, const float* x, int N, int C,
               const GruW& w, int HP, hipStream_t st) {
   if (p1 <= p0) return DVAE_OK;
-  hipLaunchKernelGGL(gru_fwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, p0, p1,
-                     b.prefix, b.GH, b.AGG, b.GHN, b.HV, b.Hn, x, N, C, w, HP);
+  hipLaunchKernelGGL(gru_fwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, b.R, p0, p1,
+                     b.prefix, no_gh, b.GH, b.AGG, b.GHN, b.HV, b.Hn, x, N, C, w, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
@@ -715,7 +719,7 @@ int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hip
 
 int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st) {
   if (p1 <= p0) return DVAE_OK;
-  hipLaunchKernelGGL(gru_bwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, p0, p1,
+  hipLaunchKernelGGL(gru_bwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, b.R, p0, p1,
                      b.prefix, b.GH, b.GHN, b.AGG, b.DH, b.DHn, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
@@ -836,7 +840,7 @@ int k_pair_fwd(const SchedView& sv, int R, const float* A, const float* Bq, cons
   return DVAE_OK;
 }
 
-int k_pair_bwd_a(const SchedView& sv, int RH, const float* A, const float* Bq, const float* Cq,
+int k_pair_bwd_a(const SchedView& sv, int R, int RH, const float* A, const float* Bq, const float* Cq,
                  const float* w2, const float* d_edge, float* DA, float* out, float* part,
                  size_t part_floats, int EHP, hipStream_t st) {
   if (RH <= 0) return DVAE_OK;
@@ -844,7 +848,7 @@ int k_pair_bwd_a(const SchedView& sv, int RH, const float* A, const float* Bq, c
   int grid = std::min(cdiv(RH, 4), 512);
   grid = (int)std::min<size_t>(grid, part_floats / (per * 4));
   DVAE_REQUIRE(grid >= 1, "pair_bwd_a: scratch too small");
-  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_a_kernel<V>), dim3(grid), dim3(256), 0, st, sv, RH, A, Bq, Cq,
+  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_a_kernel<V>), dim3(grid), dim3(256), 0, st, sv, R, RH, A, Bq, Cq,
                                        w2, d_edge, DA, part));
   DVAE_LAUNCH_CHECK();
   return reduce_parts(part, grid * 4, per, out, per, st);

@@ -31,5 +31,15 @@ struct SchedView {
   SchedDir dir[2];    // 0 forward, 1 reverse
 };
 
-// decoder prefix rows of node row r: prow(r,k) = csr_ptr[r] + r + k, k = 0..deg(r)
+// Decoder prefix rows of node row r (k = 0..deg(r), k predecessors summed):
+//   prow(r,0) = r                       -- h_in = 0 (or h0 for node 0): no hidden GEMM
+//   prow(r,k) = R + csr_ptr[r] + k - 1  -- one row per edge
+// so both classes are contiguous per level: [ls[L], ls[L+1]) and R + [es[L], es[L+1]).
+__host__ __device__ static inline int prow_of(const SchedDir& S, int R, int r, int k) {
+  return k == 0 ? r : R + S.csr_ptr[r] + k - 1;
+}
+__host__ __device__ static inline int final_prow(const SchedDir& S, int R, int r) {
+  const int e1 = S.csr_ptr[r + 1];
+  return e1 == S.csr_ptr[r] ? r : R + e1 - 1;
+}
 SchedView sched_view(void* base, int B, int N);

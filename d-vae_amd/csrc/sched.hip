@@ -265,8 +265,10 @@ __global__ __launch_bounds__(64) void sched_fill_kernel(SchedView s, int d) {
       }
     }
     if (d == 0) {
-      const int p0 = S.csr_ptr[row] + row;
-      for (int k = 0; k <= deg; ++k) S.prow_node[p0 + k] = row;
+      // decoder prefix rows: k = 0 is the node row itself, k >= 1 is R + edge index
+      const int R = S.pos[(size_t)s.N * s.B];
+      S.prow_node[row] = row;
+      for (int k = 0; k < deg; ++k) S.prow_node[R + S.csr_ptr[row] + k] = row;
     }
     // successors of node i, ascending index
     const uint32_t* sm = succb + ((size_t)b * N + i) * DVAE_BITW;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64) void sched_fill_kernel(SchedView s, int d) {
           }
           const int degj = S.csr_ptr[rj + 1] - S.csr_ptr[rj];
           const int t = above + 1;
-          S.csc_prow[q] = S.csr_ptr[rj] + rj + t;
+          S.csc_prow[q] = S.pos[(size_t)s.N * s.B] + S.csr_ptr[rj] + t - 1;
           S.csc_cnt[q] = degj - t + 1;
         }
         ++q;

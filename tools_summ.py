@@ -10,7 +10,7 @@ for r in rows:
         v = n.split('gemm_f32_kernel')[1].split('(')[0]
         key = ('gemm' + v, int(r['Grid_Size_X']) // 256, r['Grid_Size_Y'])
     else:
-        key = (n.split('(')[0].replace('(anonymous namespace)::', '').replace('void ', '')[:60],)
+        key = (n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60],)
     agg[key].append(dur)
 tot = sum(sum(v) for v in agg.values())
 steps = 13.0
