@@ -51,6 +51,7 @@ SIGNATURES = {
     "dvae_dims_init": (c_int, [_P(DvaeDims)]),
     "dvae_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dvae_gemm_force_tile": (c_int, [c_int]),
     "dvae_gemm_profile": (c_int, [c_int]),
     "dvae_gemm_profile_read": (c_int, [c_void_p]),
     "dvae_sched_bytes": (c_size_t, [c_int, c_int]),
@@ -68,10 +69,10 @@ SIGNATURES = {
     "dvae_unpack_grads": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dvae_enc_ws_bytes": (c_size_t, [_P(DvaeDims), c_int, c_int]),
     "dvae_encoder_fwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 12),
-    "dvae_encoder_bwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 11),
+    "dvae_encoder_bwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 12),
     "dvae_dec_ws_bytes": (c_size_t, [_P(DvaeDims), c_int, c_int]),
-    "dvae_decoder_fwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 11),
-    "dvae_decoder_bwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 12),
+    "dvae_decoder_fwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 12),
+    "dvae_decoder_bwd": (c_int, [_P(DvaeDims)] + [c_void_p] * 13),
     "dvae_reparam_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     "dvae_reparam_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     "dvae_elbo_ws_bytes": (c_size_t, [c_int]),

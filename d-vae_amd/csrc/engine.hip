@@ -1,7 +1,16 @@
 // Host orchestration of the level-synchronous encoder / teacher-forced decoder
-// (forward and backward).  Everything here is launches on the caller's stream;
-// no allocation, no synchronisation.
+// (forward and backward).  Everything here is launches on the caller's streams;
+// no allocation, no synchronisation with the host.
+//
+// Two streams: the per-level chain (aggregate -> hidden GEMM -> GRU epilogue ->
+// gate/map GEMM) is a sequence of mid-sized launches that cannot fill 256 CUs on
+// their own, so everything that does not sit on that chain -- the add_edge
+// first-layer products in the forward pass, every weight-gradient product in the
+// backward pass -- is issued on `side` and ordered against the chain with events.
+// side == NULL (or == stream) runs everything in order on one stream.
 #include <algorithm>
+#include <functional>
+#include <vector>
 
 #include "layout.h"
 
@@ -48,13 +57,24 @@ void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP, int 
   }
 }
 
+// scratch that a stream owns while it runs GEMMs / column reductions
+struct Scratch { float* gemm_ws; float* part; size_t part_floats; };
+
 struct EncWs {
   SweepBufs f, r;
   float *HVF, *ML, *DML, *DHVF;
   float *HVC, *CAT, *DHVC, *DCAT;   // bidirectional chain
-  float* gemm_ws; float* part; size_t part_floats;
+  Scratch sc[2];
   size_t bytes;
 };
+
+void carve_scratch(Carver& c, const dvae_dims& d, Scratch* sc) {
+  for (int i = 0; i < 2; ++i) {
+    sc[i].gemm_ws = c.f(GEMM_WS_BYTES / 4);
+    sc[i].part_floats = part_floats_for(d);
+    sc[i].part = c.f(sc[i].part_floats);
+  }
+}
 
 EncWs enc_ws(const dvae_dims& d, int R, int E, void* base) {
   EncWs w;
@@ -76,9 +96,7 @@ EncWs enc_ws(const dvae_dims& d, int R, int E, void* base) {
     w.HVC = w.CAT = w.DHVC = w.DCAT = nullptr;
     w.HVF = c.f(B * d.HP);
   }
-  w.gemm_ws = c.f(GEMM_WS_BYTES / 4);
-  w.part_floats = part_floats_for(d);
-  w.part = c.f(w.part_floats);
+  carve_scratch(c, d, w.sc);
   w.bytes = c.off;
   return w;
 }
@@ -88,7 +106,7 @@ struct DecWs {
   float *ZPAD, *H0, *DH0, *DZP;
   float *A, *DA, *Bq, *DBq, *Cq, *DCq;
   float *GS, *DGS, *VH, *DVH, *TL, *DTL;
-  float* gemm_ws; float* part; size_t part_floats;
+  Scratch sc[2];
   size_t bytes;
 };
 
@@ -113,12 +131,34 @@ DecWs dec_ws(const dvae_dims& d, int R, int E, void* base) {
   w.DVH = c.f(r * d.VHP);
   w.TL = c.f(r * d.CP);
   w.DTL = c.f(r * d.CP);
-  w.gemm_ws = c.f(GEMM_WS_BYTES / 4);
-  w.part_floats = part_floats_for(d);
-  w.part = c.f(w.part_floats);
+  carve_scratch(c, d, w.sc);
   w.bytes = c.off;
   return w;
 }
+
+// ---- stream ordering --------------------------------------------------------
+// Event pool for cross-stream edges.  hipStreamWaitEvent captures the event's
+// state when it is enqueued, so an event may be re-recorded once every wait on
+// it has been enqueued; the pool is deep enough that this always holds here.
+struct Events {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  int edge(hipStream_t from, hipStream_t to) {   // `to` continues after what `from` has queued so far
+    if (from == to) return DVAE_OK;
+    if (ev.size() < 256) {
+      hipEvent_t e;
+      DVAE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev.push_back(e);
+      next = ev.size() - 1;
+    } else {
+      next = (next + 1) % ev.size();
+    }
+    DVAE_CHECK_HIP(hipEventRecord(ev[next], from));
+    DVAE_CHECK_HIP(hipStreamWaitEvent(to, ev[next], 0));
+    return DVAE_OK;
+  }
+};
+thread_local Events g_events;
 
 // ---- GEMM shorthands ---------------------------------------------------------
 struct G {
@@ -135,7 +175,7 @@ struct G {
     GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
-  // dW[M][N] = dY[K][M]^T X[K][N]   (K = rows)
+  // dW[M][N] (+)= dY[K][M]^T X[K][N]   (K = rows)
   int tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, int K,
          int acc = 0) const {
     if (K <= 0) {
@@ -179,12 +219,15 @@ struct SweepW {
   GruW gru; const float* gm;   // gm: Wgm|posb (None) or WgmT|bgm (bn)
 };
 
+// called after the GRU states of rows [p0,p1) and of nodes [ns,ne) are final
+using LevelHook = std::function<int(int p0, int p1, int ns, int ne)>;
+
 // level sweep forward (dvae_model.py:63-87 / :93-116 / the final-state part of :196-249).
 // Row classes of a prefix (decoder) sweep, see sched.h: node rows [ls[L], ls[L+1]) carry
 // the k = 0 states (h_in = 0, or h0 for node 0 -> only level 0 needs the hidden GEMM);
 // edge rows R + [es[L], es[L+1]) carry the running predecessor sums.
 int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
-              const float* x, const float* h0, const G& g) {
+              const float* x, const float* h0, const G& g, const LevelHook& hook = nullptr) {
   const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
@@ -206,21 +249,27 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
       DVAE_TRY(k_gru_fwd(S, R, b.RH, 0, b, x, d.N, d.C, w.gru, HP, st));
     }
+    if (hook) DVAE_TRY(hook(0, b.RH, 0, R));
     return DVAE_OK;
   }
   // rows whose h_in is 0 depend on nothing but the node type: all levels in one launch
-  if (b.prefix) DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
+  if (b.prefix) {
+    DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
+    if (hook) DVAE_TRY(hook(z1, R, 0, 0));
+  }
   for (int L = 0; L < lv.nlev; ++L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
+    int p0 = ns, p1 = ne;
     DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st));
     if (L == 0) {
       if (h0) DVAE_TRY(hidden_gemm(ns, ne));
       DVAE_TRY(k_gru_fwd(S, ns, ne, h0 ? 0 : 1, b, x, d.N, d.C, w.gru, HP, st));
     } else {
-      const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
+      if (b.prefix) { p0 = R + lv.es[L]; p1 = R + lv.es[L + 1]; }
       DVAE_TRY(hidden_gemm(p0, p1));
       DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));
     }
+    if (hook) DVAE_TRY(hook(p0, p1, ns, ne));
     if (L + 1 < lv.nlev) {   // nodes of the last level have no successors
       DVAE_TRY(g.nt(b.Hn + (size_t)ns * HP, HP, w.gm, HP, b.GMP + (size_t)ns * 2 * HP, 2 * HP, ne - ns, 2 * HP,
                     HP));
@@ -324,7 +373,7 @@ extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* 
   const Levels lf = levels_of(d, info, 0);
   EncWs w = enc_ws(d, lf.R, lf.E, ws);
   const EncLayout L = enc_layout(d);
-  const G g{w.gemm_ws, st};
+  const G g{w.sc[0].gemm_ws, st};
   const int HP = d.HP, B = d.B;
 
   SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
@@ -363,25 +412,31 @@ extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* 
 
 extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* sizes, const void* sched,
                                 const int* info, const float* P, void* ws, const float* d_hv,
-                                const float* d_mu, const float* d_logvar, float* Gp, void* stream) {
+                                const float* d_mu, const float* d_logvar, float* Gp, void* stream,
+                                void* side_stream) {
   DVAE_REQUIRE(dp && x && sched && P && ws && Gp, "encoder_bwd: null pointer");
   const dvae_dims& d = *dp;
   DVAE_TRY(check_info(d, info));
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
   const SchedView sv = sched_view(const_cast<void*>(sched), d.B, d.N);
   const Levels lf = levels_of(d, info, 0);
   EncWs w = enc_ws(d, lf.R, lf.E, ws);
   const EncLayout L = enc_layout(d);
-  const G g{w.gemm_ws, st};
+  const G g{w.sc[0].gemm_ws, st};
+  const G gs{w.sc[1].gemm_ws, sd};       // weight-gradient products
+  const Scratch& ssc = w.sc[1];
+  Events& ev = g_events;
   const int HP = d.HP, B = d.B, ZP = d.ZP;
 
   // heads
   DVAE_TRY(k_pad_rows(d_mu, B, d.Z, w.DML, 2 * ZP, ZP, st));
   DVAE_TRY(k_pad_rows(d_logvar, B, d.Z, w.DML + ZP, 2 * ZP, ZP, st));
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(gs.tn(w.DML, 2 * ZP, w.HVF, HP, Gp + L.Wml, HP, 2 * ZP, HP, B));
+  DVAE_TRY(k_colsum(w.DML, 2 * ZP, B, 2 * ZP, Gp + L.bml, ssc.part, ssc.part_floats, sd));
   DVAE_TRY(g.nn(w.DML, 2 * ZP, P + L.Wml, HP, w.DHVF, HP, B, HP, 2 * ZP));
   if (d_hv) DVAE_TRY(k_add_rows(w.DHVF, HP, d_hv, d.H, B, d.H, st));
-  DVAE_TRY(g.tn(w.DML, 2 * ZP, w.HVF, HP, Gp + L.Wml, HP, 2 * ZP, HP, B));
-  DVAE_TRY(k_colsum(w.DML, 2 * ZP, B, 2 * ZP, Gp + L.bml, w.part, w.part_floats, st));
 
   DVAE_CHECK_HIP(hipMemsetAsync(w.f.DH, 0, (size_t)std::max(lf.R, 1) * HP * 4, st));
   SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
@@ -404,15 +459,20 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     }
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVC, w.f.DH, HP, st));
     // dW01 over all N*B chain rows, db01
-    DVAE_TRY(g.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
-    DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, w.part, w.part_floats, st));
+    DVAE_TRY(ev.edge(st, sd));
+    DVAE_TRY(gs.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
+    DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, ssc.part, ssc.part_floats, sd));
     DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g));
-    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b, false, g));
+    DVAE_TRY(ev.edge(st, sd));
+    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b,
+                         false, gs));
   } else {
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
   DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g));
-  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, false, g));
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, false,
+                       gs));
   return DVAE_OK;
 }
 
@@ -423,32 +483,42 @@ extern "C" size_t dvae_dec_ws_bytes(const dvae_dims* d, int R, int E) { return d
 
 extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float* x, const int* sizes,
                                 const void* sched, const int* info, const float* P, void* ws,
-                                float* edge_logits, float* type_logits, float* states, void* stream) {
+                                float* edge_logits, float* type_logits, float* states, void* stream,
+                                void* side_stream) {
   (void)sizes;
   DVAE_REQUIRE(dp && z && x && sched && P && ws && edge_logits && type_logits, "decoder_fwd: null pointer");
   const dvae_dims& d = *dp;
   DVAE_TRY(check_info(d, info));
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
   const SchedView sv = sched_view(const_cast<void*>(sched), d.B, d.N);
   const SchedDir& S = sv.dir[0];
   const Levels lv = levels_of(d, info, 0);
   DecWs w = dec_ws(d, lv.R, lv.E, ws);
   const DecLayout L = dec_layout(d);
-  const G g{w.gemm_ws, st};
-  const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E;
+  const G g{w.sc[0].gemm_ws, st};
+  const G gs{w.sc[1].gemm_ws, sd};
+  Events& ev = g_events;
+  const int HP = d.HP, B = d.B, R = lv.R, EHP = d.EHP;
 
   // h0 = lin1(z) (dvae_model.py:194)
   DVAE_TRY(k_pad_rows(z, B, d.Z, w.ZPAD, d.ZP, d.ZP, st));
   DVAE_TRY(g.nt(w.ZPAD, d.ZP, P + L.Wl1, d.ZP, w.H0, HP, B, HP, d.ZP, P + L.bl1));
+  if (d.mod) {
+    DVAE_TRY(ev.edge(st, sd));
+    DVAE_TRY(gs.nt(w.H0, HP, P + L.W1c, HP, w.Cq, EHP, B, EHP, HP));
+  }
+  // add_edge's first layer, split by input block (dvae_model.py:211-218), follows the
+  // sweep level by level on the side stream
   SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
-  DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g));
-
-  // add_edge: first layer split by input block (dvae_model.py:211-218)
-  DVAE_TRY(g.nt(w.s.HV, HP, P + L.W1a, HP, w.A, d.EHP, RH, d.EHP, HP));
-  DVAE_TRY(g.nt(w.s.Hn, HP, P + L.W1b, HP, w.Bq, d.EHP, R, d.EHP, HP, P + L.b1));
-  if (d.mod) DVAE_TRY(g.nt(w.H0, HP, P + L.W1c, HP, w.Cq, d.EHP, B, d.EHP, HP));
-  DVAE_CHECK_HIP(hipMemsetAsync(edge_logits, 0, (size_t)B * d.N * d.N * 4, st));
-  DVAE_TRY(k_pair_fwd(sv, R, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, d.EHP, st));
+  LevelHook hook = [&](int p0, int p1, int ns, int ne) -> int {
+    DVAE_TRY(ev.edge(st, sd));
+    DVAE_TRY(gs.nt(w.s.HV + (size_t)p0 * HP, HP, P + L.W1a, HP, w.A + (size_t)p0 * EHP, EHP, p1 - p0, EHP, HP));
+    DVAE_TRY(gs.nt(w.s.Hn + (size_t)ns * HP, HP, P + L.W1b, HP, w.Bq + (size_t)ns * EHP, EHP, ne - ns, EHP, HP,
+                   P + L.b1));
+    return DVAE_OK;
+  };
+  DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g, hook));
 
   // add_vertex on the graph state seen before each node (dvae_model.py:199-200,251-257)
   DVAE_TRY(k_graph_state_fwd(S, R, d.N, d.mod, w.s.Hn, w.H0, w.GS, HP, st));
@@ -460,46 +530,56 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
     DVAE_TRY(k_rows_to_dense(S, R, w.s.Hn, HP, states, d.N, d.H, st));
   }
+  // pair scores need every A / Bq row
+  DVAE_CHECK_HIP(hipMemsetAsync(edge_logits, 0, (size_t)B * d.N * d.N * 4, st));
+  DVAE_TRY(ev.edge(sd, st));
+  DVAE_TRY(k_pair_fwd(sv, R, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
   return DVAE_OK;
 }
 
 extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float* x, const int* sizes,
                                 const void* sched, const int* info, const float* P, void* ws,
                                 const float* d_edge, const float* d_type, float* Gp, float* d_z,
-                                void* stream) {
+                                void* stream, void* side_stream) {
   (void)z;
   DVAE_REQUIRE(dp && x && sched && P && ws && d_edge && d_type && Gp, "decoder_bwd: null pointer");
   const dvae_dims& d = *dp;
   DVAE_TRY(check_info(d, info));
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
   const SchedView sv = sched_view(const_cast<void*>(sched), d.B, d.N);
   const SchedDir& S = sv.dir[0];
   const Levels lv = levels_of(d, info, 0);
   DecWs w = dec_ws(d, lv.R, lv.E, ws);
   const DecLayout L = dec_layout(d);
-  const G g{w.gemm_ws, st};
+  const G g{w.sc[0].gemm_ws, st};
+  const G gs{w.sc[1].gemm_ws, sd};       // weight-gradient products
+  const Scratch& msc = w.sc[0];
+  const Scratch& ssc = w.sc[1];
+  Events& ev = g_events;
   const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E, EHP = d.EHP;
 
   // ---- add_edge ----
-  DVAE_TRY(k_pair_bwd_a(sv, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, w.part, w.part_floats, EHP, st));
+  DVAE_TRY(k_pair_bwd_a(sv, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part, msc.part_floats,
+                        EHP, st));
   DVAE_TRY(k_pair_bwd_b(sv, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
+  if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
+  DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, R));
+  DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
+  if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
   DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
-  DVAE_TRY(g.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
-  DVAE_TRY(g.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, R));
-  DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, w.part, w.part_floats, st));
-  if (d.mod) {
-    DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
-    DVAE_TRY(g.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
-  }
   // ---- add_vertex ----
   DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, st));
   DVAE_TRY(g.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
   DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, st));
-  DVAE_TRY(g.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
-  DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, w.part, w.part_floats, st));
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(gs.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
+  DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, ssc.part, ssc.part_floats, sd));
+  DVAE_TRY(gs.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
+  DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, ssc.part, ssc.part_floats, sd));
   DVAE_TRY(g.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
-  DVAE_TRY(g.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
-  DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, w.part, w.part_floats, st));
   DVAE_CHECK_HIP(hipMemsetAsync(w.DH0, 0, (size_t)B * HP * 4, st));
   DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
   // the W1b half of add_edge reads the final states
@@ -508,13 +588,14 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   // ---- level sweep ----
   SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
   DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
-  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, g));
 
   // ---- lin1 ----
   DVAE_TRY(g.tn(w.DH0, HP, w.ZPAD, d.ZP, Gp + L.Wl1, d.ZP, HP, d.ZP, B));
-  DVAE_TRY(k_colsum(w.DH0, HP, B, HP, Gp + L.bl1, w.part, w.part_floats, st));
+  DVAE_TRY(k_colsum(w.DH0, HP, B, HP, Gp + L.bl1, msc.part, msc.part_floats, st));
   if (d_z) {
     DVAE_TRY(g.nn(w.DH0, HP, P + L.Wl1, d.ZP, w.DZP, d.ZP, B, d.ZP, HP));
     DVAE_TRY(k_unpad_rows(w.DZP, d.ZP, B, d.Z, d_z, st));

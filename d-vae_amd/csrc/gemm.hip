@@ -300,6 +300,9 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
 
 }  // namespace
 
+static int g_force_tile = 0;   // tuning knob (tests/bench_gemm.py): 0 auto, 1 128x128, 2 64x128, 3 64x64
+extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE_OK; }
+
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0) return DVAE_OK;
   DVAE_REQUIRE(d.K > 0, "gemm: K must be positive");
@@ -313,8 +316,11 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   // tile choice: narrow outputs take 128x32; otherwise the shape that needs the
   // fewest "rounds" of 256 CUs (fp32 MFMA time is proportional to tile area)
   const bool narrow = d.N <= 32;
-  bool half = false;
-  if (!narrow) {
+  bool half = false, quarter = false;
+  if (g_force_tile == 1) half = false;
+  else if (g_force_tile == 2) half = true;
+  else if (g_force_tile == 3) quarter = true;
+  else if (!narrow) {
     const long long t128 = (long long)cdiv(d.M, 128) * cdiv(d.N, 128);
     const long long t64 = (long long)cdiv(d.M, 64) * cdiv(d.N, 128);
     const long long c128 = ((t128 + 255) / 256) * 2, c64 = (t64 + 255) / 256;
@@ -322,6 +328,7 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   }
 #define GEMM_PICK(AK, BKK)                                                     \
   return narrow ? launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream)      \
+         : quarter ? launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream)    \
          : half ? launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream)      \
                 : launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream)
   if (!d.a_kmajor && !d.b_kmajor) { GEMM_PICK(0, 0); }

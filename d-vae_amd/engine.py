@@ -20,6 +20,11 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _side(side):
+    """torch.cuda.Stream (or None) -> hipStream_t for the library's side stream."""
+    return None if side is None else ctypes.c_void_p(side.cuda_stream)
+
+
 def _require_cuda(t, name):
     if not t.is_cuda:
         raise _lib.DvaeError(
@@ -182,15 +187,15 @@ class EncoderCall:
                                    _ptr(P), _ptr(self.ws), _ptr(self.hv), _ptr(self.mu), _ptr(self.logvar),
                                    _ptr(self.states), _ptr(self.states_rev), _stream()))
 
-    def backward(self, d_hv, d_mu, d_logvar, G):
+    def backward(self, d_hv, d_mu, d_logvar, G, side=None):
         s = self.sched
         check(load().dvae_encoder_bwd(ctypes.byref(self.dims), _ptr(self.x), _ptr(s.sizes), _ptr(s.buf), s.info_ptr,
                                       _ptr(self.P), _ptr(self.ws), _ptr(d_hv), _ptr(d_mu), _ptr(d_logvar),
-                                      _ptr(G), _stream()))
+                                      _ptr(G), _stream(), _side(side)))
 
 
 class DecoderCall:
-    def __init__(self, dims, sched, z, x, P, want_states=False):
+    def __init__(self, dims, sched, z, x, P, want_states=False, side=None):
         lib = load()
         self.dims, self.sched, self.z, self.x, self.P = dims, sched, z, x, P
         dev = x.device
@@ -201,14 +206,14 @@ class DecoderCall:
         self.states = torch.empty(B, N, dims.H, device=dev) if want_states else None
         check(lib.dvae_decoder_fwd(ctypes.byref(dims), _ptr(z), _ptr(x), _ptr(sched.sizes), _ptr(sched.buf),
                                    sched.info_ptr, _ptr(P), _ptr(self.ws), _ptr(self.edge_logits),
-                                   _ptr(self.type_logits), _ptr(self.states), _stream()))
+                                   _ptr(self.type_logits), _ptr(self.states), _stream(), _side(side)))
 
-    def backward(self, d_edge, d_type, G, want_dz=True):
+    def backward(self, d_edge, d_type, G, want_dz=True, side=None):
         s = self.sched
         d_z = torch.empty_like(self.z) if want_dz else None
         check(load().dvae_decoder_bwd(ctypes.byref(self.dims), _ptr(self.z), _ptr(self.x), _ptr(s.sizes), _ptr(s.buf),
                                       s.info_ptr, _ptr(self.P), _ptr(self.ws), _ptr(d_edge), _ptr(d_type), _ptr(G),
-                                      _ptr(d_z), _stream()))
+                                      _ptr(d_z), _stream(), _side(side)))
         return d_z
 
 

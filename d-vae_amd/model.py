@@ -211,6 +211,7 @@ class Dvae(nn.Module):
         self._shared_gm = bool(kw)
         self.beta = getattr(hparams, 'beta', 0.005)
         self._flat = None
+        self._side = None
 
     # -- reference API -------------------------------------------------------
     def reparamterize(self, mu, logvar, eps=None):
@@ -324,25 +325,37 @@ class Dvae(nn.Module):
             Pe = enc._pack.pack(d_enc, enc_p)
             Pd = dec._pack.pack(d_dec, dec_p)
             fe, fd = self._flat_grads()
+            main = torch.cuda.current_stream()
+            if self._side is None or self._side.device != main.device:
+                self._side = torch.cuda.Stream(device=main.device)
+            side = self._side
+            side.wait_stream(main)
+            handles = []
             ec = E.EncoderCall(d_enc, sched, xs, Pe)
             if eps is None:
                 eps = torch.randn_like(ec.mu)
             z = E.reparam_fwd(ec.mu, ec.logvar, eps)
-            dc = E.DecoderCall(d_dec, sched, z, xs, Pd)
+            dc = E.DecoderCall(d_dec, sched, z, xs, Pd, side=side)
             out4, (ge, gt, gmu, glv) = E.elbo_call(d_dec, dc.edge_logits, dc.type_logits, sched.g, xs, sched.sizes,
                                                    ec.mu, ec.logvar, float(beta), True)
             Gd = dec._pack.new_packed_grad()
-            d_z = dc.backward(ge, gt, Gd)
-            dec._pack.unpack(Gd, fd)
-            handles = [grad_sync(fd)] if grad_sync is not None else []
+            Ge = enc._pack.new_packed_grad()
+            # the weight-gradient products run on `side` beside the per-level chains; the
+            # decoder's unpack + all-reduce are queued there too, under the encoder's backward
+            d_z = dc.backward(ge, gt, Gd, side=side)
+            with torch.cuda.stream(side):
+                dec._pack.unpack(Gd, fd)
+                if grad_sync is not None:
+                    handles.append(grad_sync(fd))
             dmu, dlv = E.reparam_bwd(d_z, ec.logvar, eps)
             gmu.add_(dmu)
             glv.add_(dlv)
-            Ge = enc._pack.new_packed_grad()
-            ec.backward(None, gmu, glv, Ge)
-            enc._pack.unpack(Ge, fe)
-            if grad_sync is not None:
-                handles.append(grad_sync(fe))
+            ec.backward(None, gmu, glv, Ge, side=side)
+            with torch.cuda.stream(side):
+                enc._pack.unpack(Ge, fe)
+                if grad_sync is not None:
+                    handles.append(grad_sync(fe))
+            main.wait_stream(side)
             for p, v in zip(enc_p, enc._pack.views(fe, enc_p)):
                 p.grad = v
             for p, v in zip(dec_p, dec._pack.views(fd, dec_p)):

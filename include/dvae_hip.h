@@ -72,6 +72,7 @@ int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb
  * every GEMM launch is bracketed by HIP events on its own stream.
  * dvae_gemm_profile_read waits for them and fills out12 = 4 x {launches, ms,
  * executed flops} indexed by layout (0 NT, 1 NN, 3 TN), then clears the log. */
+int dvae_gemm_force_tile(int mode);   /* tuning knob: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
 int dvae_gemm_profile(int enable);
 int dvae_gemm_profile_read(double* out12_host);
 
@@ -156,10 +157,17 @@ size_t dvae_enc_ws_bytes(const dvae_dims* d, int R, int E);
 int dvae_encoder_fwd(const dvae_dims* d, const float* x, const int* sizes, const void* sched,
                      const int* info_host, const float* P, void* ws, float* hv, float* mu,
                      float* logvar, float* states, float* states_rev, void* stream);
-/* d_hv/d_mu/d_logvar: upstream gradients (any may be NULL); G: packed grads out */
+/* d_hv/d_mu/d_logvar: upstream gradients (any may be NULL); G: packed grads out.
+ * side_stream (hipStream_t or NULL): when given, the products that are off the
+ * per-level chain (add_edge first layer in decoder_fwd, every weight-gradient
+ * product in the *_bwd calls) are issued there and ordered with events; on return
+ * `side_stream` may still hold work that writes G / edge_logits' inputs, so the
+ * caller orders its next use of G after it (hipStreamWaitEvent).  decoder_fwd
+ * joins the side stream itself before it returns. */
 int dvae_encoder_bwd(const dvae_dims* d, const float* x, const int* sizes, const void* sched,
                      const int* info_host, const float* P, void* ws, const float* d_hv,
-                     const float* d_mu, const float* d_logvar, float* G, void* stream);
+                     const float* d_mu, const float* d_logvar, float* G, void* stream,
+                     void* side_stream);
 
 /* ------------------------------------------------------------------------
  * Teacher-forced decoder (dvae_model.py:178-261).
@@ -169,11 +177,12 @@ int dvae_encoder_bwd(const dvae_dims* d, const float* x, const int* sizes, const
 size_t dvae_dec_ws_bytes(const dvae_dims* d, int R, int E);
 int dvae_decoder_fwd(const dvae_dims* d, const float* z, const float* x, const int* sizes,
                      const void* sched, const int* info_host, const float* P, void* ws,
-                     float* edge_logits, float* type_logits, float* states, void* stream);
+                     float* edge_logits, float* type_logits, float* states, void* stream,
+                     void* side_stream);
 int dvae_decoder_bwd(const dvae_dims* d, const float* z, const float* x, const int* sizes,
                      const void* sched, const int* info_host, const float* P, void* ws,
                      const float* d_edge_logits, const float* d_type_logits, float* G, float* d_z,
-                     void* stream);
+                     void* stream, void* side_stream);
 
 /* ------------------------------------------------------------------------
  * Reparameterise (dvae_model.py:410-413) with injected eps, and its backward.
