@@ -1,0 +1,92 @@
+"""CPU: the oracle (oracle/dense_ref.py, oracle/levels.py) against the golden
+vectors produced by the real reference (tests/golden/make_golden.py)."""
+import glob
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import fill_weights, oracle_sd
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRAIN_CASES = ["enas_val8_none_bidir", "rand8_none_uni", "rand10_bn_bidir_shared"]
+
+
+def load_case(name):
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    mod = None if str(d['mod']) == 'None' else str(d['mod'])
+    return d, mod, bool(d['bidir']), bool(d['shared'])
+
+
+def build_model(d, mod, bidir, shared, device=None):
+    import dvae_amd
+    N, C = d['x'].shape[1], d['x'].shape[2]
+    hp = Namespace(dataset_file=None, mod=mod, bidirectional=bidir, num_classes=C, max_seq=N,
+                   same_mapper_gater=shared)
+    model = fill_weights(dvae_amd.Dvae(hp), int(d['seed']))
+    return model.to(device) if device is not None else model
+
+
+def test_fixture_inventory():
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
+    assert names == sorted(TRAIN_CASES + ["predict_none", "predict_bn"])
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_oracle_matches_reference(name):
+    from oracle import dense_ref as O
+    from oracle import levels as OL
+    d, mod, bidir, shared = load_case(name)
+    model = build_model(d, mod, bidir, shared)
+    sd = oracle_sd(model, requires_grad=True)
+    g, x, eps = (torch.from_numpy(d[k]) for k in ('g', 'x', 'eps'))
+    hv, mu, lv, fw, bw = O.encoder_forward(sd, g, x, mod, bidir, return_states=True)
+    tol = dict(rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(fw.detach().numpy(), d['enc_states'], **tol)
+    if bidir:
+        np.testing.assert_allclose(bw.detach().numpy(), d['enc_states_rev'], **tol)
+    np.testing.assert_allclose(hv.detach().numpy(), d['hv'], **tol)
+    np.testing.assert_allclose(mu.detach().numpy(), d['mu'], **tol)
+    np.testing.assert_allclose(lv.detach().numpy(), d['logvar'], **tol)
+    z = O.reparameterize(mu, lv, eps)
+    np.testing.assert_allclose(z.detach().numpy(), d['z'], **tol)
+    e, t, hd, _ = O.decoder_forward(sd, torch.from_numpy(d['z']), g, x, mod, return_states=True)
+    np.testing.assert_allclose(hd.detach().numpy(), d['dec_states'], **tol)
+    np.testing.assert_allclose(e.detach().numpy(), d['edge_logits'], **tol)
+    np.testing.assert_allclose(t.detach().numpy(), d['type_logits'], **tol)
+    o = O.train_loss(sd, g, x, eps, mod, bidir)
+    np.testing.assert_allclose([float(o[1]), float(o[2]), float(o[3]), float(o[0])], d['losses'], rtol=1e-5)
+    o[0].backward()
+    seen = set()
+    for k in sd:
+        if 'gval/' + k not in d or id(sd[k]) in seen:
+            continue
+        seen.add(id(sd[k]))
+        got = sd[k].grad.flatten().double()
+        np.testing.assert_allclose(got[torch.from_numpy(d['gidx/' + k])].numpy(), d['gval/' + k],
+                                   rtol=2e-4, atol=1e-6 * max(1.0, float(d['gsum/' + k][1])))
+        assert abs(float(got.sum()) - d['gsum/' + k][0]) <= 2e-4 * max(1e-3, d['gsum/' + k][1])
+    # level definition
+    assert np.array_equal(OL.forward_levels(d['g']), d['levels_fwd'])
+    assert np.array_equal(OL.reverse_levels(d['g']), d['levels_rev'])
+
+
+def test_enas_fixture_is_a_depth7_chain():
+    d, *_ = load_case("enas_val8_none_bidir")
+    assert (d['levels_fwd'].max(axis=1) == 7).all()          # every ENAS graph is a depth-7 chain
+
+
+@pytest.mark.parametrize("name", ["predict_none", "predict_bn"])
+def test_oracle_predict_matches_reference(name):
+    import dvae_amd
+    from oracle import dense_ref as O
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    mod = None if str(d['mod']) == 'None' else str(d['mod'])
+    N, C = int(d['N']), int(d['C'])
+    hp = Namespace(dataset_file=None, mod=mod, bidirectional=False, num_classes=C, max_seq=N)
+    model = fill_weights(dvae_amd.Dvae(hp), int(d['seed']))
+    with torch.no_grad():
+        edges, types = O.decoder_predict(oracle_sd(model), torch.from_numpy(d['z']), N, C, mod)
+    assert np.array_equal(edges.numpy(), d['edges']) and np.array_equal(types.numpy(), d['types'])
