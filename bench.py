@@ -106,20 +106,19 @@ def main():
             dist.broadcast(p.data, 0)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
 
+    from dvae_amd import dp
     # a few distinct batches per rank, generated once, resident in HBM
     nb = 4
     batches, e_sum = [], 0.0
     for i in range(nb):
         g, x = dvae_amd.synth.enas_like(B_global, 100 + i)
-        sl = slice(rank * B_local, (rank + 1) * B_local)
+        lo, hi = dp.shard_range(B_global, rank, world)
+        sl = slice(lo, hi)
         e_sum += float(g[sl].sum()) / B_local
         batches.append({'graph': g[sl].to(dev), 'node_encoding': x[sl].to(dev)})
     mean_e = e_sum / nb
 
-    def sync_grads(flat):
-        if dist is None:
-            return None
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)   # losses are sums (dvae_model.py:405)
+    sync_grads = dp.make_grad_sync(dist)       # SUM all-reduce: the losses are sums (dvae_model.py:405)
 
     def step(i):
         out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads)

@@ -139,6 +139,13 @@ def main():
     g = torch.stack([it['graph'] for it in items])
     x = torch.stack([it['node_encoding'] for it in items])
     run_case("enas_val8_none_bidir", None, True, False, 8, 8, g, x, seed=101)
+    # the same 8 rows as raw text + their row numbers: pins the parser / split of d-vae_amd/data.py
+    lines = [ln.strip() for ln in open('/root/reference/dvae/data/final_structures6.txt') if ln.strip()]
+    idx = ds.samples.index.to_numpy()[:8]
+    np.savez_compressed(os.path.join(HERE, "enas_rows.npz"), n_rows=np.int64(len(lines)), val_index=idx,
+                        lines=np.array([lines[i] for i in idx]), acc=np.array([it['acc'] for it in items]),
+                        n_train=np.int64(len(NASDataset('/root/reference/dvae/data/final_structures6.txt', split='train'))),
+                        n_test=np.int64(len(NASDataset('/root/reference/dvae/data/final_structures6.txt', split='test'))))
     # (ii) random lower-triangular DAGs, uni-directional
     g, x = dvae_amd.synth.random_dags(8, 8, 8, 0.4, seed=5)
     run_case("rand8_none_uni", None, False, False, 8, 8, g, x, seed=102)

@@ -31,7 +31,7 @@ def build_model(d, mod, bidir, shared, device=None):
 
 def test_fixture_inventory():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
-    assert names == sorted(TRAIN_CASES + ["predict_none", "predict_bn"])
+    assert names == sorted(TRAIN_CASES + ["predict_none", "predict_bn", "enas_rows"])
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -90,3 +90,25 @@ def test_oracle_predict_matches_reference(name):
     with torch.no_grad():
         edges, types = O.decoder_predict(oracle_sd(model), torch.from_numpy(d['z']), N, C, mod)
     assert np.array_equal(edges.numpy(), d['edges']) and np.array_equal(types.numpy(), d['types'])
+
+
+def test_dataset_parser_and_split(tmp_path):
+    """d-vae_amd/data.py against the reference's NASDataset (dataloader.py:10-108) on real ENAS rows."""
+    from dvae_amd import data
+    r = np.load(os.path.join(GOLD, "enas_rows.npz"))
+    d = np.load(os.path.join(GOLD, "enas_val8_none_bidir.npz"))
+    for k, line in enumerate(r['lines']):
+        rows, acc = data.parse_line(str(line))
+        g, x = data.encode_structure(rows, 'enas')
+        assert np.array_equal(g.numpy(), d['g'][k]) and np.array_equal(x.numpy(), d['x'][k])
+        assert acc == r['acc'][k]
+    idx = data.split_indices(int(r['n_rows']))
+    assert np.array_equal(idx['val'][:8], r['val_index'])
+    assert len(idx['train']) == int(r['n_train']) and len(idx['test']) == int(r['n_test'])
+    # loaders: same tuple shape as the reference (val is a 1-tuple)
+    f = tmp_path / "rows.txt"
+    f.write_text("\n".join(str(l) for l in r['lines']) + "\n")
+    tr, va, te = data.get_dataloaders(2, str(f))
+    assert isinstance(va, tuple) and len(va) == 1
+    b = next(iter(tr))
+    assert b['graph'].shape == (2, 8, 8) and b['node_encoding'].shape == (2, 8, 8) and b['acc'].dtype == torch.float64
