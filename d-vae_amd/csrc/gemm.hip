@@ -19,6 +19,8 @@
 //
 // The k order inside an 8-wide chunk is permuted (lane half h owns k = 4h..4h+3)
 // consistently for A and B, which only reorders the fp32 summation.
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -359,14 +361,29 @@ extern "C" int dvae_gemm_profile(int enable) {
 
 extern "C" int dvae_gemm_profile_read(double* out12) {
   for (int i = 0; i < 12; ++i) out12[i] = 0.0;
+  // slot 2 (layout index 2 is unused): out12[6] = wall time during which at least one GEMM
+  // launch was running -- launches on the two streams overlap, so the per-launch sum
+  // counts such time twice
+  std::vector<std::pair<double, double>> iv;
   for (size_t i = 0; i < g_prof.used; ++i) {
     GemmProf& r = g_prof.recs[i];
     DVAE_CHECK_HIP(hipEventSynchronize(r.b));
-    float ms = 0.f;
+    float ms = 0.f, t0 = 0.f;
     DVAE_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
     double* o = out12 + 3 * (r.variant & 3);
     o[0] += 1.0; o[1] += ms; o[2] += r.flops;
+    if (hipEventElapsedTime(&t0, g_prof.recs[0].a, r.a) == hipSuccess) iv.push_back({t0, (double)t0 + ms});
   }
+  std::sort(iv.begin(), iv.end());
+  double busy = 0.0, cur_lo = 0.0, cur_hi = -1.0;
+  for (auto& p : iv) {
+    if (p.first > cur_hi) {
+      if (cur_hi > cur_lo) busy += cur_hi - cur_lo;
+      cur_lo = p.first; cur_hi = p.second;
+    } else if (p.second > cur_hi) cur_hi = p.second;
+  }
+  if (cur_hi > cur_lo) busy += cur_hi - cur_lo;
+  out12[6] = busy;
   g_prof.used = 0;
   return DVAE_OK;
 }

@@ -71,7 +71,9 @@ int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb
 /* Instrumentation for bench.py (no counterpart in the reference): while enabled,
  * every GEMM launch is bracketed by HIP events on its own stream.
  * dvae_gemm_profile_read waits for them and fills out12 = 4 x {launches, ms,
- * executed flops} indexed by layout (0 NT, 1 NN, 3 TN), then clears the log. */
+ * executed flops} indexed by layout (0 NT, 1 NN, 3 TN), then clears the log;
+ * out12[6] (the unused layout slot) = wall milliseconds during which at least
+ * one GEMM launch was running (launches on the two streams overlap). */
 int dvae_gemm_force_tile(int mode);   /* tuning knob: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
 int dvae_gemm_profile(int enable);
 int dvae_gemm_profile_read(double* out12_host);
