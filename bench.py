@@ -87,8 +87,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("DVAE_FORCE_DIST"))    # exercise the RCCL path on one GPU (rehearsal)
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -101,7 +103,7 @@ def main():
 
     torch.manual_seed(0)
     model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=None, bidirectional=False)).to(dev)
-    if world > 1:
+    if dist is not None:
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
@@ -118,7 +120,7 @@ def main():
         batches.append({'graph': g[sl].to(dev), 'node_encoding': x[sl].to(dev)})
     mean_e = e_sum / nb
 
-    sync_grads = dp.make_grad_sync(dist)       # SUM all-reduce: the losses are sums (dvae_model.py:405)
+    sync_grads = dp.make_grad_sync(dist, force=force_dist)       # SUM all-reduce: the losses are sums (dvae_model.py:405)
 
     def step(i):
         out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads)

@@ -18,10 +18,10 @@ def shard_batch(batch, rank, world):
     return {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n else v) for k, v in batch.items()}
 
 
-def make_grad_sync(dist, group=None):
+def make_grad_sync(dist, group=None, force=False):
     """Callable for Dvae.loss_and_grad(grad_sync=...): asynchronous SUM all-reduce of one
     flat gradient buffer on whatever stream is current (RCCL on GPUs, gloo on CPU)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return None
 
     def sync(flat):
