@@ -272,6 +272,12 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   int splits = 1;
   if (p.nblk < 256 && d.K >= 2048 && ws) {
     splits = min(cdiv(768, p.nblk), d.K / 512);
+  } else if (p.nblk <= 128 && d.K >= 512 && ws) {
+    // small-batch per-level products: a handful of tiles, each walking the whole K
+    // loop at one workgroup per CU, is latency-bound -- spread K over the idle CUs
+    splits = min(cdiv(256, p.nblk), d.K / 128);
+  }
+  if (splits > 1) {
     const size_t slab = (size_t)d.M * d.N * sizeof(float);
     if (slab == 0) return DVAE_OK;
     splits = (int)min((size_t)splits, ws_bytes / slab);

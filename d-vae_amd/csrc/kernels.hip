@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ X,
 
 // chunking: at most `maxc` chunks of at least 128 rows, bounded by the scratch
 inline void chunking(int rows, size_t per_chunk, size_t part_floats, int maxc, int* nch, int* rpc) {
-  int n = std::max(1, std::min(maxc, cdiv(rows, 128)));
+  int n = std::max(1, std::min(maxc, cdiv(rows, 32)));
   if (per_chunk > 0) n = (int)std::max<size_t>(1, std::min<size_t>(n, part_floats / per_chunk));
   *rpc = std::max(1, cdiv(rows, n));
   *nch = std::max(1, cdiv(rows, *rpc));
