@@ -52,6 +52,7 @@ SIGNATURES = {
     "dvae_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dvae_gemm_force_tile": (c_int, [c_int]),
+    "dvae_gemm_tune": (c_int, [c_int, c_int]),
     "dvae_gemm_profile": (c_int, [c_int]),
     "dvae_gemm_profile_read": (c_int, [c_void_p]),
     "dvae_sched_bytes": (c_size_t, [c_int, c_int]),
@@ -79,6 +80,8 @@ SIGNATURES = {
     "dvae_elbo": (c_int, [_P(DvaeDims)] + [c_void_p] * 7 + [c_float] + [c_void_p] * 7),
     "dvae_predict_ws_bytes": (c_size_t, [_P(DvaeDims)]),
     "dvae_decoder_predict": (c_int, [_P(DvaeDims)] + [c_void_p] * 9),
+    "dvae_side_stream_create": (c_int, [_P(c_void_p), _P(c_int)]),
+    "dvae_side_stream_destroy": (c_int, [c_void_p]),
 }
 
 _lib = None

@@ -56,6 +56,7 @@ struct GemmDesc {
   const float* bias;   // per column n, or null
   int relu;            // apply max(0,.) after bias
   int accumulate;      // C += result
+  int prio;            // 1: waves run at raised priority (launches on the per-level chain)
 };
 // C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);

@@ -9,6 +9,7 @@
 // backward pass -- is issued on `side` and ordered against the chain with events.
 // side == NULL (or == stream) runs everything in order on one stream.
 #include <algorithm>
+#include <cstdlib>
 #include <functional>
 #include <vector>
 
@@ -162,17 +163,17 @@ thread_local Events g_events;
 
 // ---- GEMM shorthands ---------------------------------------------------------
 struct G {
-  float* ws; hipStream_t st;
+  float* ws; hipStream_t st; int prio = 0;
   // Y[M][N] (+)= X[M][K] W[N][K]^T + bias
   int nt(const float* X, int ldx, const float* W, int ldw, float* Y, int ldy, int M, int N, int K,
          const float* bias = nullptr, int relu = 0, int acc = 0) const {
-    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc};
+    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dX[M][N] (+)= dY[M][K] W[K][N]
   int nn(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K,
          int acc = 0) const {
-    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc};
+    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dW[M][N] (+)= dY[K][M]^T X[K][N]   (K = rows)
@@ -186,7 +187,7 @@ struct G {
       }
       return DVAE_OK;
     }
-    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc};
+    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc, prio};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
 };
@@ -279,9 +280,39 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   return DVAE_OK;
 }
 
+// Weight-gradient products of the square matrices (W_hh, [Wg;Wm]) issued level by level
+// on the side stream while the reverse sweep is still running, so that only the last
+// level's products remain after the sweep (the first product writes, the rest accumulate
+// in level order: deterministic).
+struct LevelWgrad {
+  const G* gs; Events* ev; float* Ggru; float* Ggm;
+  bool wrote_gru = false, wrote_gm = false;
+  int gru_rows(hipStream_t st, const SweepBufs& b, int HP, int p0, int p1) {
+    if (p1 <= p0) return DVAE_OK;
+    DVAE_TRY(ev->edge(st, gs->st));
+    DVAE_TRY(gs->tn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, b.AGG + (size_t)p0 * HP, HP, Ggru, HP, 3 * HP, HP, p1 - p0,
+                    wrote_gru ? 1 : 0));
+    wrote_gru = true;
+    return DVAE_OK;
+  }
+  int gm_rows(hipStream_t st, const SweepBufs& b, int HP, int ns, int ne) {
+    if (ne <= ns) return DVAE_OK;
+    DVAE_TRY(ev->edge(st, gs->st));
+    DVAE_TRY(gs->tn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, b.Hn + (size_t)ns * HP, HP, Ggm, HP, 2 * HP, HP, ne - ns,
+                    wrote_gm ? 1 : 0));
+    wrote_gm = true;
+    return DVAE_OK;
+  }
+};
+
 // reverse-level sweep: DH holds dL/dHV on entry, dL/dAGG on exit
+// `pre(L)` (decoder): called before level L is processed; it must leave dL/dHV of the level's
+// prefix rows in DH and the level's extra final-state gradient in DHn.  pre(-1) covers the
+// k = 0 rows of levels >= 1, which are only needed after the loop.
+using PreLevel = std::function<int(int L)>;
+
 int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
-              bool seeded, const G& g) {
+              bool seeded, const G& g, LevelWgrad* wg = nullptr, const PreLevel& pre = nullptr) {
   const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
@@ -303,35 +334,48 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   float* dtarget = b.prefix ? b.DHn : b.DH;
   for (int L = lv.nlev - 1; L >= 0; --L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
+    if (pre) DVAE_TRY(pre(L));
     if (L + 1 < lv.nlev) {
       DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
+      if (wg) DVAE_TRY(wg->gm_rows(st, b, HP, ns, ne));
       DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
                     2 * HP, 1));
     }
     if (L == 0) {
       DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st));
-      if (seeded) DVAE_TRY(dagg_gemm(ns, ne));      // only node 0's h_in = h0 needs it
+      if (seeded) {                                  // only node 0's h_in = h0 needs it
+        if (wg) DVAE_TRY(wg->gru_rows(st, b, HP, ns, ne));
+        DVAE_TRY(dagg_gemm(ns, ne));
+      }
     } else {
       const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
       DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
+      if (wg) DVAE_TRY(wg->gru_rows(st, b, HP, p0, p1));
       DVAE_TRY(dagg_gemm(p0, p1));
     }
   }
   // k = 0 rows of the later levels feed nothing backwards except the weight gradients
-  if (b.prefix) DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
+  if (b.prefix) {
+    if (pre) DVAE_TRY(pre(-1));
+    DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
+  }
   return DVAE_OK;
 }
 
 // weight gradients of one sweep, reduced over all rows after the sweep.
 // Ggru -> dWhh [3HP][HP]; Xgru / Xgm -> the gradient-only regions of layout.h
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g) {
+                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g,
+                const LevelWgrad* done = nullptr) {
   const int HP = d.HP, PP = pos_cols(d), R = lv.R;
   hipStream_t st = g.st;
   const int RH = R > 0 ? b.RH : 0;
   const int z1 = (R > 0 && lv.nlev > 0) ? lv.ls[1] : 0;
   // dWhh = dgh^T . h_in over the rows whose h_in is not identically zero
-  if (!b.prefix) {
+  if (done) {
+    // the sweep already issued these level by level; cover the "no rows at all" case
+    if (!done->wrote_gru) DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, 0));
+  } else if (!b.prefix) {
     const int skip = d.mod == 0 ? z1 : 0;      // level 0 of a node sweep has h_in = 0
     DVAE_TRY(g.tn(b.GH + (size_t)skip * 3 * HP, 3 * HP, b.AGG + (size_t)skip * HP, HP, Ggru, HP, 3 * HP, HP,
                   R - skip));
@@ -345,7 +389,8 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
   DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xgru + (size_t)3 * HP * 32, 32, HP, 32, RH));
   if (d.mod == 0) {
     const int Rg = lv.nlev > 0 ? lv.ls[lv.nlev - 1] : 0;   // nodes that have a gate/map output
-    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
+    if (!done) DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
+    else if (!done->wrote_gm) DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, 0));
     DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
     DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, PP, Xgm, PP, 2 * HP, PP, Rg));
   } else {
@@ -373,7 +418,7 @@ extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* 
   const Levels lf = levels_of(d, info, 0);
   EncWs w = enc_ws(d, lf.R, lf.E, ws);
   const EncLayout L = enc_layout(d);
-  const G g{w.sc[0].gemm_ws, st};
+  const G g{w.sc[0].gemm_ws, st, 1};
   const int HP = d.HP, B = d.B;
 
   SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
@@ -423,11 +468,12 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
   const Levels lf = levels_of(d, info, 0);
   EncWs w = enc_ws(d, lf.R, lf.E, ws);
   const EncLayout L = enc_layout(d);
-  const G g{w.sc[0].gemm_ws, st};
+  const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
   const G gs{w.sc[1].gemm_ws, sd};       // weight-gradient products
   const Scratch& ssc = w.sc[1];
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, ZP = d.ZP;
+  const bool per_level = d.mod == 0;   // see LevelWgrad (same summation order with or without a side stream)
 
   // heads
   DVAE_TRY(k_pad_rows(d_mu, B, d.Z, w.DML, 2 * ZP, ZP, st));
@@ -462,17 +508,19 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     DVAE_TRY(ev.edge(st, sd));
     DVAE_TRY(gs.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
     DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, ssc.part, ssc.part_floats, sd));
-    DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g));
+    LevelWgrad wgr{&gs, &ev, Gp + L.gru_b, Gp + L.gm_b};
+    DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g, per_level ? &wgr : nullptr));
     DVAE_TRY(ev.edge(st, sd));
     DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b,
-                         false, gs));
+                         false, gs, per_level ? &wgr : nullptr));
   } else {
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
-  DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g));
+  LevelWgrad wgf{&gs, &ev, Gp + L.gru_f, Gp + L.gm_f};
+  DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g, per_level ? &wgf : nullptr));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, false,
-                       gs));
+                       gs, per_level ? &wgf : nullptr));
   return DVAE_OK;
 }
 
@@ -496,7 +544,7 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
   const Levels lv = levels_of(d, info, 0);
   DecWs w = dec_ws(d, lv.R, lv.E, ws);
   const DecLayout L = dec_layout(d);
-  const G g{w.sc[0].gemm_ws, st};
+  const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
   const G gs{w.sc[1].gemm_ws, sd};
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, R = lv.R, EHP = d.EHP;
@@ -552,44 +600,68 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const Levels lv = levels_of(d, info, 0);
   DecWs w = dec_ws(d, lv.R, lv.E, ws);
   const DecLayout L = dec_layout(d);
-  const G g{w.sc[0].gemm_ws, st};
+  const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
   const G gs{w.sc[1].gemm_ws, sd};       // weight-gradient products
   const Scratch& msc = w.sc[0];
   const Scratch& ssc = w.sc[1];
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E, EHP = d.EHP;
 
-  // ---- add_edge ----
+  // ---- add_edge / add_vertex: everything that feeds the level sweep stays on `st`,
+  // every weight-gradient product goes to the (low-priority) side stream at once ----
   DVAE_TRY(k_pair_bwd_a(sv, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part, msc.part_floats,
                         EHP, st));
   DVAE_TRY(k_pair_bwd_b(sv, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
+  DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, st));
+  DVAE_TRY(g.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
+  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, st));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
   DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, R));
   DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
-  DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
-  // ---- add_vertex ----
-  DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, st));
-  DVAE_TRY(g.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
-  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, st));
-  DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(gs.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
   DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, ssc.part, ssc.part_floats, sd));
   DVAE_TRY(gs.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
   DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, ssc.part, ssc.part_floats, sd));
+  // the graph state seen by add_vertex at node i is the state of node i-1 (bn: all earlier
+  // nodes), which may sit in any level: this product cannot follow the sweep level by level
   DVAE_TRY(g.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
   DVAE_CHECK_HIP(hipMemsetAsync(w.DH0, 0, (size_t)B * HP * 4, st));
   DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
-  // the W1b half of add_edge reads the final states
-  DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, R, HP, EHP, 1));
 
-  // ---- level sweep ----
+  // ---- level sweep; the add_edge input gradients (dA.W1a -> dL/dHV of the prefix rows,
+  // dBq.W1b -> the final states) are produced level by level just ahead of it, so the
+  // sweep starts after the last level's slice instead of after the whole product ----
   SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
-  DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
+  const int z1 = (R > 0 && lv.nlev > 0) ? lv.ls[1] : R;
+  auto dh_rows = [&](int p0, int p1) {
+    return g.nn(w.DA + (size_t)p0 * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)p0 * HP, HP, p1 - p0, HP, EHP);
+  };
+  auto dhn_rows = [&](int ns, int ne) {
+    return g.nn(w.DBq + (size_t)ns * EHP, EHP, P + L.W1b, HP, w.s.DHn + (size_t)ns * HP, HP, ne - ns, HP, EHP, 1);
+  };
+  PreLevel pre = [&](int Lv) -> int {
+    if (Lv < 0) return dh_rows(z1, R);
+    DVAE_TRY(dhn_rows(lv.ls[Lv], lv.ls[Lv + 1]));
+    if (Lv == 0) return dh_rows(0, z1);
+    return dh_rows(R + lv.es[Lv], R + lv.es[Lv + 1]);
+  };
+  const bool per_level = d.mod == 0;   // see LevelWgrad (same summation order with or without a side stream)
+  LevelWgrad wgl{&gs, &ev, Gp + L.gru, Gp + L.gm};
+  if (R > 0) {
+    if (d.mod == 1 || lv.nlev <= 0) {   // one "level": whole products
+      DVAE_TRY(dh_rows(0, RH));
+      DVAE_TRY(dhn_rows(0, R));
+      DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, nullptr));
+    } else {
+      DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, per_level ? &wgl : nullptr, pre));
+    }
+  }
   DVAE_TRY(ev.edge(st, sd));
-  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs));
+  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs,
+                       per_level ? &wgl : nullptr));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
 
@@ -600,5 +672,26 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     DVAE_TRY(g.nn(w.DH0, HP, P + L.Wl1, d.ZP, w.DZP, d.ZP, B, d.ZP, HP));
     DVAE_TRY(k_unpad_rows(w.DZP, d.ZP, B, d.Z, d_z, st));
   }
+  return DVAE_OK;
+}
+
+// ===========================================================================
+// side stream
+// ===========================================================================
+extern "C" int dvae_side_stream_create(void** stream_out, int* priority_out) {
+  DVAE_REQUIRE(stream_out, "side_stream_create: null pointer");
+  int least = 0, greatest = 0;
+  DVAE_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  int prio = least;
+  if (const char* e = getenv("DVAE_SIDE_PRIORITY")) prio = std::max(std::min(atoi(e), least), greatest);   // tuning
+  hipStream_t s;
+  DVAE_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+  *stream_out = (void*)s;
+  if (priority_out) *priority_out = prio;
+  return DVAE_OK;
+}
+
+extern "C" int dvae_side_stream_destroy(void* stream) {
+  if (stream) DVAE_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
   return DVAE_OK;
 }

@@ -25,26 +25,54 @@
 
 #include "common.h"
 
+static int g_splitk_blocks = 768;   // tuning knob: workgroups a split-K launch aims for
+static int g_force_prio = -1;       // tuning knob: -1 as requested by the caller, 0/1 override
+static int g_dbg = 0;
+extern "C" int dvae_gemm_dbg(int v) { g_dbg = v; return 0; }
+static int g_variant = 0;           // tuning knob: 0 BK32 1-stage, 1 BK16 2-stage, 2 BK32 2-stage, 3 BK16 1-stage
+extern "C" int dvae_gemm_variant(int v) { g_variant = v; return 0; }
+
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDM = BK + 4;  // row stride of an m-major LDS tile, floats
-
-template <int KM, int ROWS>
+template <int KM, int ROWS, int BK>
 struct Tile {
+  static constexpr int LDM = BK + 4;              // row stride of an m-major LDS tile, floats
+  static constexpr int KQ = BK / 4;               // float4 per tile row
   static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
+  static_assert(NV >= 1, "tile too small for 256 threads");
   static constexpr int LDS_FLOATS = KM ? BK * ROWS : ROWS * LDM;
   float4 v[NV];
 
   // rows: extent of the non-reduction dim; kend: end of this block's k range.
+  // CHECK = false: the caller guarantees that the k range [k0, k0+BK) lies inside the
+  // reduction; row indices beyond `rows` are clamped to the last valid row(s), whose
+  // products land in output rows the epilogue never stores.  No predicates, no branches.
+  template <bool CHECK>
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int rows, int k0,
                                        int kend, int tid) {
+    if (!CHECK) {
+      if (KM == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int r = min(r0 + tid / KQ + i * (256 / KQ), rows - 1);
+          v[i] = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k0 + (tid % KQ) * 4);
+        }
+      } else {
+        constexpr int RQ = ROWS / 4;
+        const int r = min(r0 + (tid % RQ) * 4, rows - 4);
+        const float* base = P + (size_t)(k0 + tid / RQ) * ld + r;
+        const size_t step = (size_t)(256 / RQ) * ld;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(base + i * step);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (KM == 0) {
-        const int row = idx >> 3, kq = idx & 7;
+        const int row = idx / KQ, kq = idx % KQ;
         const int r = r0 + row, k = k0 + kq * 4;
         if (r < rows && k < kend) val = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k);
       } else {
@@ -62,7 +90,7 @@ struct Tile {
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
       if (KM == 0) {
-        const int row = idx >> 3, kq = idx & 7;
+        const int row = idx / KQ, kq = idx % KQ;
         *reinterpret_cast<float4*>(lds + row * LDM + kq * 4) = v[i];
       } else {
         constexpr int RQ = ROWS / 4;
@@ -93,6 +121,8 @@ struct GemmParams {
   int k_chunk;            // k range per blockIdx.y
   long long c_split;      // C offset (floats) per blockIdx.y
   int tiles_n, nblk;
+  int dbg;                // lab only
+  int prio;               // wave priority (s_setprio): the per-level chain outranks the bulk side-stream products
 };
 
 // bijective XCD-aware remap: blocks that share blockIdx%8 (one XCD under
@@ -105,18 +135,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + j;
 }
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
-  using TA = Tile<AKM, BM>;
-  using TB = Tile<BKM, BN>;
-  // one LDS stage (two barriers per k-tile): a second stage measured 5-34 % slower
-  // on this chip because it drops residency from three workgroups per CU to two
-  __shared__ __attribute__((aligned(16))) float lds[TA::LDS_FLOATS + TB::LDS_FLOATS];
-  float* As = lds;
-  float* Bs = lds + TA::LDS_FLOATS;
+  using TA = Tile<AKM, BM, BK>;
+  using TB = Tile<BKM, BN, BK>;
+  // ST = 1: one LDS stage, two barriers per k-tile.  ST = 2: two stages, one barrier per
+  // k-tile -- a wave refills the other stage as soon as its own MFMAs of this tile are issued.
+  constexpr int STAGE = TA::LDS_FLOATS + TB::LDS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[ST * STAGE];
 
+  // issue arbitration between co-resident waves goes by priority, then age: without this a
+  // long-running bulk workgroup (older) starves the short chain launches that share its CU
+  if (p.prio) __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -138,18 +170,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
 
   TA ta;
   TB tb;
-  ta.load(p.A, p.lda, m0, p.M, kb, ke, tid);
-  tb.load(p.B, p.ldb, n0, p.N, kb, ke, tid);
-  ta.store(As, tid);
-  tb.store(Bs, tid);
+  ta.template load<true>(p.A, p.lda, m0, p.M, kb, ke, tid);
+  tb.template load<true>(p.B, p.ldb, n0, p.N, kb, ke, tid);
+  ta.store(lds, tid);
+  tb.store(lds + TA::LDS_FLOATS, tid);
   __syncthreads();
 
-  for (int k0 = kb; k0 < ke; k0 += BK) {
-    const bool more = (k0 + BK) < ke;
-    if (more) {
-      ta.load(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
-      tb.load(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
-    }
+  int cur = 0;
+  auto compute = [&]() {
+    const float* As = lds + cur * STAGE;
+    const float* Bs = As + TA::LDS_FLOATS;
 #pragma unroll
     for (int kc = 0; kc < BK / 8; ++kc) {
       float4 af[TM], bf[TN];
@@ -161,42 +191,98 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          // the n-operand goes first: the accumulator then holds C^T, i.e. each lane owns
+          // runs of 4 consecutive n for one m, and the epilogue stores float4
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j].x, af[i].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j].y, af[i].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j].z, af[i].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j].w, af[i].w, acc[i][j], 0, 0, 0);
         }
     }
-    __syncthreads();
-    if (more) {
-      ta.store(As, tid);
-      tb.store(Bs, tid);
+  };
+  auto refill = [&]() {   // registers -> LDS for the next k-tile
+    if (ST == 1) {
       __syncthreads();
+      ta.store(lds, tid);
+      tb.store(lds + TA::LDS_FLOATS, tid);
+      __syncthreads();
+    } else {
+      float* nx = lds + (cur ^ 1) * STAGE;
+      ta.store(nx, tid);
+      tb.store(nx + TA::LDS_FLOATS, tid);
+      __syncthreads();
+      cur ^= 1;
     }
-  }
+  };
 
-  // epilogue.  C/D map of the 32x32 MFMA: col = lane&31,
-  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  int k0 = kb;
+  // hot loop: the next k-tile is a full one, loaded without predicates or branches (a loop
+  // body with both load forms makes the compiler wait for the loads where the forms merge)
+  for (; k0 + 2 * BK <= ke; k0 += BK) {
+    if (!(p.dbg & 2)) {
+      ta.template load<false>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
+      tb.template load<false>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
+    }
+    compute();
+    refill();
+  }
+  // the last one or two k-tiles (a ragged reduction ends in a partial tile)
+  for (; k0 < ke; k0 += BK) {
+    const bool more = (k0 + BK) < ke;
+    if (more) {
+      ta.template load<true>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
+      tb.template load<true>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
+    }
+    compute();
+    if (more) refill();
+  }
+  if (ST == 1) __syncthreads();
+
+  // epilogue.  D map of the 32x32 MFMA with the operands as above:
+  // m = lane&31, n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  ->  reg group g holds n = 8g + 4*(lane>>5) + 0..3
   float* C = p.C + (size_t)blockIdx.y * p.c_split;
+  if ((p.dbg & 1) && acc[0][0][0] != 12345.f) return;
+  const bool vec = ((p.ldc | p.N) & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                   (!p.bias || ((uintptr_t)p.bias & 15) == 0);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    const int row = m0 + wm * (BM / WM) + i * 32 + (lane & 31);
+    if (row >= p.M) continue;
+    float* crow = C + (size_t)row * p.ldc;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < p.M) {
-          float v = acc[i][j][r] + bv;
-          float* dst = C + (size_t)row * p.ldc + col;
-          if (p.accumulate) v += *dst;
-          if (p.relu) v = fmaxf(v, 0.f);
+      for (int g = 0; g < 4; ++g) {
+        const int col = n0 + wn * (BN / WN) + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (col >= p.N) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (vec) {
+          if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          float4* dst = reinterpret_cast<float4*>(crow + col);
+          if (p.accumulate) {
+            const float4 o = *dst;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          if (p.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
           *dst = v;
+        } else {
+          const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (col + t >= p.N) break;
+            float x = e[t] + (p.bias ? p.bias[col + t] : 0.f);
+            if (p.accumulate) x += crow[col + t];
+            if (p.relu) x = fmaxf(x, 0.f);
+            crow[col + t] = x;
+          }
         }
       }
-    }
+  }
 }
 
 // out[m][n] (+)= sum_s slab[s][m][n] + bias[n]
@@ -256,13 +342,15 @@ void prof_end(GemmProf* r, hipStream_t st) {
   if (r) (void)hipEventRecord(r->b, st);
 }
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1>
 int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   GemmParams p;
   p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias;
   p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.relu = d.relu; p.accumulate = d.accumulate;
+  p.prio = g_force_prio >= 0 ? g_force_prio : d.prio;
+  p.dbg = g_dbg;
   const int tiles_m = cdiv(d.M, BM);
   p.tiles_n = cdiv(d.N, BN);
   p.nblk = tiles_m * p.tiles_n;
@@ -271,7 +359,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   // weight-gradient products: small [out][in] result, reduction over all rows)
   int splits = 1;
   if (p.nblk < 256 && d.K >= 2048 && ws) {
-    splits = min(cdiv(768, p.nblk), d.K / 512);
+    splits = min(cdiv(g_splitk_blocks, p.nblk), d.K / 512);
   } else if (p.nblk <= 128 && d.K >= 512 && ws) {
     // small-batch per-level products: a handful of tiles, each walking the whole K
     // loop at one workgroup per CU, is latency-bound -- spread K over the idle CUs
@@ -292,7 +380,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     p.c_split = 0;
   }
   GemmProf* pr = prof_begin(AKM * 2 + BKM, 2.0 * d.M * d.N * d.K, stream);
-  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN>), dim3(p.nblk, splits), dim3(256), 0,
+  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST>), dim3(p.nblk, splits), dim3(256), 0,
                      stream, p);
   prof_end(pr, stream);
   DVAE_LAUNCH_CHECK();
@@ -308,6 +396,11 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int dvae_gemm_tune(int splitk_blocks, int force_prio) {
+  if (splitk_blocks > 0) g_splitk_blocks = splitk_blocks;
+  g_force_prio = force_prio;
+  return DVAE_OK;
+}
 static int g_force_tile = 0;   // tuning knob (tests/bench_gemm.py): 0 auto, 1 128x128, 2 64x128, 3 64x64
 extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE_OK; }
 
@@ -334,11 +427,20 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
     const long long c128 = ((t128 + 255) / 256) * 2, c64 = (t64 + 255) / 256;
     half = c64 < c128 && t128 < 2048 && !(d.K >= 2048 && t128 < 256 && ws);   // split-K fills the chip instead
   }
-#define GEMM_PICK(AK, BKK)                                                     \
-  return narrow ? launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream)      \
-         : quarter ? launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream)    \
-         : half ? launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream)      \
-                : launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream)
+#define GEMM_PICK(AK, BKK)                                                                   \
+  if (narrow) return launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream);                \
+  if (quarter) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);                \
+  if (g_variant == 1)                                                                        \
+    return half ? launch<AK, BKK, 64, 128, 1, 4, 16, 2>(d, ws, ws_bytes, stream)             \
+                : launch<AK, BKK, 128, 128, 2, 2, 16, 2>(d, ws, ws_bytes, stream);           \
+  if (g_variant == 2)                                                                        \
+    return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 2>(d, ws, ws_bytes, stream)             \
+                : launch<AK, BKK, 128, 128, 2, 2, 32, 2>(d, ws, ws_bytes, stream);           \
+  if (g_variant == 3)                                                                        \
+    return half ? launch<AK, BKK, 64, 128, 1, 4, 16, 1>(d, ws, ws_bytes, stream)             \
+                : launch<AK, BKK, 128, 128, 2, 2, 16, 1>(d, ws, ws_bytes, stream);           \
+  return half ? launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream)                      \
+              : launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream)
   if (!d.a_kmajor && !d.b_kmajor) { GEMM_PICK(0, 0); }
   if (!d.a_kmajor && d.b_kmajor) { GEMM_PICK(0, 1); }
   if (d.a_kmajor && d.b_kmajor) { GEMM_PICK(1, 1); }
@@ -355,6 +457,7 @@ extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float*
   d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
   d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
   d.bias = bias; d.relu = relu; d.accumulate = accumulate;
+  d.prio = 0;
   return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
 }
 

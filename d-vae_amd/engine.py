@@ -25,6 +25,23 @@ def _side(side):
     return None if side is None else ctypes.c_void_p(side.cuda_stream)
 
 
+_side_streams = {}
+
+
+def side_stream(device):
+    """The library's low-priority side stream of `device` (one per device per
+    process), wrapped as a torch stream so torch ops / RCCL can be queued on it."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _side_streams:
+        raw, prio = ctypes.c_void_p(), ctypes.c_int()
+        with torch.cuda.device(idx):
+            check(load().dvae_side_stream_create(ctypes.byref(raw), ctypes.byref(prio)))
+        _side_streams[idx] = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
+    return _side_streams[idx]
+
+
 def _require_cuda(t, name):
     if not t.is_cuda:
         raise _lib.DvaeError(

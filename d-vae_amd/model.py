@@ -326,9 +326,7 @@ class Dvae(nn.Module):
             Pd = dec._pack.pack(d_dec, dec_p)
             fe, fd = self._flat_grads()
             main = torch.cuda.current_stream()
-            if self._side is None or self._side.device != main.device:
-                self._side = torch.cuda.Stream(device=main.device)
-            side = self._side
+            side = E.side_stream(main.device)
             side.wait_stream(main)
             handles = []
             ec = E.EncoderCall(d_enc, sched, xs, Pe)

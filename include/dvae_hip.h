@@ -75,6 +75,8 @@ int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb
  * out12[6] (the unused layout slot) = wall milliseconds during which at least
  * one GEMM launch was running (launches on the two streams overlap). */
 int dvae_gemm_force_tile(int mode);   /* tuning knob: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
+int dvae_gemm_tune(int splitk_blocks, int force_prio);   /* tuning knobs: workgroups a split-K launch aims for
+                                                           (0 = keep), wave priority override (-1 = caller's) */
 int dvae_gemm_profile(int enable);
 int dvae_gemm_profile_read(double* out12_host);
 
@@ -185,6 +187,14 @@ int dvae_decoder_bwd(const dvae_dims* d, const float* z, const float* x, const i
                      const void* sched, const int* info_host, const float* P, void* ws,
                      const float* d_edge_logits, const float* d_type_logits, float* G, float* d_z,
                      void* stream, void* side_stream);
+
+/* Side stream for the *_fwd / *_bwd calls above (no counterpart in the reference).
+ * It is created with the LOWEST scheduling priority the device offers, so that the
+ * per-level chain on the caller's stream wins the CUs whenever both have work and
+ * the bulk products on the side stream fill what the chain leaves idle.
+ * priority_out (optional, host) receives the priority actually used. */
+int dvae_side_stream_create(void** stream_out, int* priority_out);
+int dvae_side_stream_destroy(void* stream);
 
 /* ------------------------------------------------------------------------
  * Reparameterise (dvae_model.py:410-413) with injected eps, and its backward.
