@@ -60,3 +60,7 @@ struct GemmDesc {
 };
 // C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);
+
+// bench.py's per-launch timing hooks (gemm.hip); begin returns NULL when profiling is off
+void* gemm_prof_begin(double flops, hipStream_t st);
+void gemm_prof_end(void* h, hipStream_t st);

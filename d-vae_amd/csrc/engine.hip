@@ -29,7 +29,7 @@ struct Carver {
 constexpr size_t GEMM_WS_BYTES = (size_t)96 << 20;
 
 size_t part_floats_for(const dvae_dims& d) {
-  size_t m = (size_t)(d.EHP + 4) * 2048;
+  size_t m = (size_t)(d.EHP + 4) * (2048 + 64);   // pair_bwd_a: one partial per wave + the group sums of its 2-stage reduction
   m = std::max(m, (size_t)d.EHP * 512);
   return m;
 }
@@ -144,8 +144,7 @@ DecWs dec_ws(const dvae_dims& d, int R, int E, void* base) {
 struct Events {
   std::vector<hipEvent_t> ev;
   size_t next = 0;
-  int edge(hipStream_t from, hipStream_t to) {   // `to` continues after what `from` has queued so far
-    if (from == to) return DVAE_OK;
+  int take(hipEvent_t* out) {   // next event of the ring
     if (ev.size() < 256) {
       hipEvent_t e;
       DVAE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -154,8 +153,15 @@ struct Events {
     } else {
       next = (next + 1) % ev.size();
     }
-    DVAE_CHECK_HIP(hipEventRecord(ev[next], from));
-    DVAE_CHECK_HIP(hipStreamWaitEvent(to, ev[next], 0));
+    *out = ev[next];
+    return DVAE_OK;
+  }
+  int edge(hipStream_t from, hipStream_t to) {   // `to` continues after what `from` has queued so far
+    if (from == to) return DVAE_OK;
+    hipEvent_t e;
+    DVAE_TRY(take(&e));
+    DVAE_CHECK_HIP(hipEventRecord(e, from));
+    DVAE_CHECK_HIP(hipStreamWaitEvent(to, e, 0));
     return DVAE_OK;
   }
 };
@@ -233,22 +239,28 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
   const int z1 = lv.nlev > 0 ? lv.ls[1] : R;   // end of level 0
-  auto hidden_gemm = [&](int p0, int p1) {
-    return g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0, 3 * HP, HP);
+  // Fused level steps (level.hip).  The gate/map step is fused by default (one launch, 25 %
+  // less time than GEMM + epilogue kernel).  The fused GRU step is parity-green but measured
+  // slower than "64x128-tile GEMM + gru_fwd_kernel" on MI355X (a workgroup must hold all three
+  // gates of its hidden units, which leaves 2 instead of 3 waves per SIMD): opt-in with
+  // DVAE_FUSED_GRU=1.  DVAE_UNFUSED=1 turns both off (A-B tests).
+  static const bool unfused = getenv("DVAE_UNFUSED") != nullptr;
+  static const bool fused_gru = !unfused && getenv("DVAE_FUSED_GRU") != nullptr;
+  auto gru_rows = [&](int p0, int p1) -> int {
+    if (fused_gru) return k_level_gru_fwd(S, p0, p1, b, x, d.N, d.C, w.gru, HP, g.prio, st);
+    DVAE_TRY(g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0, 3 * HP, HP));
+    return k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st);
   };
   if (d.mod == 1) {
     // gate/map depends on node types only: no inter-node dependency, one "level"
     DVAE_TRY(k_gm_bn_fwd(S, R, b, x, d.N, d.C, w.gm, w.gm + (size_t)d.C * 2 * HP, HP, st));
     DVAE_TRY(k_agg_fwd(S, 0, R, b, h0, HP, st));
     if (!b.prefix) {
-      DVAE_TRY(hidden_gemm(0, R));
-      DVAE_TRY(k_gru_fwd(S, 0, R, 0, b, x, d.N, d.C, w.gru, HP, st));
+      DVAE_TRY(gru_rows(0, R));
     } else {
-      DVAE_TRY(hidden_gemm(0, z1));
-      DVAE_TRY(hidden_gemm(R, b.RH));
-      DVAE_TRY(k_gru_fwd(S, 0, z1, 0, b, x, d.N, d.C, w.gru, HP, st));
+      DVAE_TRY(gru_rows(0, z1));
       DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
-      DVAE_TRY(k_gru_fwd(S, R, b.RH, 0, b, x, d.N, d.C, w.gru, HP, st));
+      DVAE_TRY(gru_rows(R, b.RH));
     }
     if (hook) DVAE_TRY(hook(0, b.RH, 0, R));
     return DVAE_OK;
@@ -263,18 +275,21 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     int p0 = ns, p1 = ne;
     DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st));
     if (L == 0) {
-      if (h0) DVAE_TRY(hidden_gemm(ns, ne));
-      DVAE_TRY(k_gru_fwd(S, ns, ne, h0 ? 0 : 1, b, x, d.N, d.C, w.gru, HP, st));
+      if (h0) DVAE_TRY(gru_rows(ns, ne));
+      else DVAE_TRY(k_gru_fwd(S, ns, ne, 1, b, x, d.N, d.C, w.gru, HP, st));
     } else {
       if (b.prefix) { p0 = R + lv.es[L]; p1 = R + lv.es[L + 1]; }
-      DVAE_TRY(hidden_gemm(p0, p1));
-      DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));
+      DVAE_TRY(gru_rows(p0, p1));
     }
     if (hook) DVAE_TRY(hook(p0, p1, ns, ne));
     if (L + 1 < lv.nlev) {   // nodes of the last level have no successors
-      DVAE_TRY(g.nt(b.Hn + (size_t)ns * HP, HP, w.gm, HP, b.GMP + (size_t)ns * 2 * HP, 2 * HP, ne - ns, 2 * HP,
-                    HP));
-      DVAE_TRY(k_gm_fwd(S, ns, ne, b, w.gm + (size_t)2 * HP * HP, HP, st));
+      if (!unfused && ne - ns >= 2048) {   // below that the fused tile grid is too small to fill the chip
+        DVAE_TRY(k_level_gm_fwd(S, ns, ne, b, w.gm, w.gm + (size_t)2 * HP * HP, HP, g.prio, st));
+      } else {
+        DVAE_TRY(g.nt(b.Hn + (size_t)ns * HP, HP, w.gm, HP, b.GMP + (size_t)ns * 2 * HP, 2 * HP, ne - ns, 2 * HP,
+                      HP));
+        DVAE_TRY(k_gm_fwd(S, ns, ne, b, w.gm + (size_t)2 * HP * HP, HP, st));
+      }
     }
   }
   return DVAE_OK;
@@ -568,20 +583,23 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
   };
   DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g, hook));
 
-  // add_vertex on the graph state seen before each node (dvae_model.py:199-200,251-257)
-  DVAE_TRY(k_graph_state_fwd(S, R, d.N, d.mod, w.s.Hn, w.H0, w.GS, HP, st));
-  DVAE_TRY(g.nt(w.GS, HP, P + L.Wv1, HP, w.VH, d.VHP, R, d.VHP, HP, P + L.bv1, 1));
-  DVAE_TRY(g.nt(w.VH, d.VHP, P + L.Wv2, d.VHP, w.TL, d.CP, R, d.CP, d.VHP, P + L.bv2));
-  DVAE_CHECK_HIP(hipMemsetAsync(type_logits, 0, (size_t)B * d.N * d.C * 4, st));
-  DVAE_TRY(k_rows_to_dense(S, R, w.TL, d.CP, type_logits, d.N, d.C, st));
+  // pair scores need every A / Bq row: the chain waits for the side stream's products here
+  DVAE_CHECK_HIP(hipMemsetAsync(edge_logits, 0, (size_t)B * d.N * d.N * 4, st));
+  DVAE_TRY(ev.edge(sd, st));
+  // add_vertex on the graph state seen before each node (dvae_model.py:199-200,251-257): MFMA
+  // work on the side stream, beside the bandwidth-bound pair scorer on the chain
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(k_graph_state_fwd(S, R, d.N, d.mod, w.s.Hn, w.H0, w.GS, HP, sd));
+  DVAE_TRY(gs.nt(w.GS, HP, P + L.Wv1, HP, w.VH, d.VHP, R, d.VHP, HP, P + L.bv1, 1));
+  DVAE_TRY(gs.nt(w.VH, d.VHP, P + L.Wv2, d.VHP, w.TL, d.CP, R, d.CP, d.VHP, P + L.bv2));
+  DVAE_CHECK_HIP(hipMemsetAsync(type_logits, 0, (size_t)B * d.N * d.C * 4, sd));
+  DVAE_TRY(k_rows_to_dense(S, R, w.TL, d.CP, type_logits, d.N, d.C, sd));
   if (states) {
     DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
     DVAE_TRY(k_rows_to_dense(S, R, w.s.Hn, HP, states, d.N, d.H, st));
   }
-  // pair scores need every A / Bq row
-  DVAE_CHECK_HIP(hipMemsetAsync(edge_logits, 0, (size_t)B * d.N * d.N * 4, st));
-  DVAE_TRY(ev.edge(sd, st));
   DVAE_TRY(k_pair_fwd(sv, R, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
+  DVAE_TRY(ev.edge(sd, st));
   return DVAE_OK;
 }
 
@@ -607,27 +625,35 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E, EHP = d.EHP;
 
-  // ---- add_edge / add_vertex: everything that feeds the level sweep stays on `st`,
-  // every weight-gradient product goes to the (low-priority) side stream at once ----
+  // ---- add_vertex backward (MFMA-bound) runs on the side stream beside the bandwidth-bound
+  // pair-scorer backward on the chain; then every weight-gradient product follows there ----
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, sd));
+  DVAE_TRY(gs.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
+  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, sd));
+  // the graph state seen by add_vertex at node i is the state of node i-1 (bn: all earlier
+  // nodes), which may sit in any level: this product cannot follow the sweep level by level
+  DVAE_TRY(gs.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
+  hipEvent_t dgs_done = nullptr;
+  if (sd != st) {
+    DVAE_TRY(ev.take(&dgs_done));
+    DVAE_CHECK_HIP(hipEventRecord(dgs_done, sd));
+  }
+  DVAE_TRY(gs.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
+  DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, ssc.part, ssc.part_floats, sd));
+  DVAE_TRY(gs.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
+  DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, ssc.part, ssc.part_floats, sd));
+
   DVAE_TRY(k_pair_bwd_a(sv, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part, msc.part_floats,
                         EHP, st));
   DVAE_TRY(k_pair_bwd_b(sv, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
-  DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, st));
-  DVAE_TRY(g.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
-  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, st));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
   DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, R));
   DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
-  DVAE_TRY(gs.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
-  DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, ssc.part, ssc.part_floats, sd));
-  DVAE_TRY(gs.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
-  DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, ssc.part, ssc.part_floats, sd));
-  // the graph state seen by add_vertex at node i is the state of node i-1 (bn: all earlier
-  // nodes), which may sit in any level: this product cannot follow the sweep level by level
-  DVAE_TRY(g.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
+  if (dgs_done) DVAE_CHECK_HIP(hipStreamWaitEvent(st, dgs_done, 0));
   DVAE_CHECK_HIP(hipMemsetAsync(w.DH0, 0, (size_t)B * HP * 4, st));
   DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
 

@@ -20,6 +20,8 @@
 // The k order inside an 8-wide chunk is permuted (lane half h owns k = 4h..4h+3)
 // consistently for A and B, which only reorders the fp32 summation.
 #include <algorithm>
+#include <deque>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -320,13 +322,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
 struct GemmProf { hipEvent_t a, b; int variant; double flops; };
 struct ProfState {
   bool on = false;
-  std::vector<GemmProf> recs;
+  std::deque<GemmProf> recs;   // references stay valid across push_back
   size_t used = 0;
 };
 ProfState g_prof;
 
+std::mutex g_prof_mu;   // micro-batches are launched from several host threads
+
 GemmProf* prof_begin(int variant, double flops, hipStream_t st) {
   if (!g_prof.on) return nullptr;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   if (g_prof.used == g_prof.recs.size()) {
     GemmProf r;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
@@ -341,6 +346,14 @@ GemmProf* prof_begin(int variant, double flops, hipStream_t st) {
 void prof_end(GemmProf* r, hipStream_t st) {
   if (r) (void)hipEventRecord(r->b, st);
 }
+}  // namespace
+
+// the fused level-step kernels (level.hip) run the same MFMA main loop and are counted
+// with the NT launches
+void* gemm_prof_begin(double flops, hipStream_t st) { return prof_begin(0, flops, st); }
+void gemm_prof_end(void* h, hipStream_t st) { prof_end(static_cast<GemmProf*>(h), st); }
+
+namespace {
 
 template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1>
 int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
@@ -414,8 +427,10 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   else DVAE_REQUIRE((d.M & 3) == 0, "gemm: M must be a multiple of 4 for a k-major A");
   if (!d.b_kmajor) DVAE_REQUIRE((d.K & 3) == 0, "gemm: K must be a multiple of 4 for an n-major B");
   else DVAE_REQUIRE((d.N & 3) == 0, "gemm: N must be a multiple of 4 for a k-major B");
-  // tile choice: narrow outputs take 128x32; otherwise the shape that needs the
-  // fewest "rounds" of 256 CUs (fp32 MFMA time is proportional to tile area)
+  // tile choice: narrow outputs take 128x32.  Otherwise the largest tile that still gives
+  // every CU two or more workgroups (measured: below that a launch is latency-bound and the
+  // next smaller tile wins), and between 128x128 and 64x128 the one that needs fewer
+  // "rounds" of 256 CUs.  Long reductions into a small output keep 128x128 and split K.
   const bool narrow = d.N <= 32;
   bool half = false, quarter = false;
   if (g_force_tile == 1) half = false;
@@ -424,21 +439,22 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   else if (!narrow) {
     const long long t128 = (long long)cdiv(d.M, 128) * cdiv(d.N, 128);
     const long long t64 = (long long)cdiv(d.M, 64) * cdiv(d.N, 128);
-    const long long c128 = ((t128 + 255) / 256) * 2, c64 = (t64 + 255) / 256;
-    half = c64 < c128 && t128 < 2048 && !(d.K >= 2048 && t128 < 256 && ws);   // split-K fills the chip instead
+    const bool splitk = d.K >= 2048 && t128 < 256 && ws;
+    if (!splitk) {
+      const long long c128 = ((t128 + 255) / 256) * 2, c64 = (t64 + 255) / 256;
+      if (t128 >= 512) half = c64 < c128 && t128 < 2048;
+      else if (t64 >= 512) half = true;
+      else quarter = true;
+    }
   }
 #define GEMM_PICK(AK, BKK)                                                                   \
   if (narrow) return launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream);                \
   if (quarter) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);                \
-  if (g_variant == 1)                                                                        \
-    return half ? launch<AK, BKK, 64, 128, 1, 4, 16, 2>(d, ws, ws_bytes, stream)             \
-                : launch<AK, BKK, 128, 128, 2, 2, 16, 2>(d, ws, ws_bytes, stream);           \
-  if (g_variant == 2)                                                                        \
-    return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 2>(d, ws, ws_bytes, stream)             \
-                : launch<AK, BKK, 128, 128, 2, 2, 32, 2>(d, ws, ws_bytes, stream);           \
-  if (g_variant == 3)                                                                        \
-    return half ? launch<AK, BKK, 64, 128, 1, 4, 16, 1>(d, ws, ws_bytes, stream)             \
-                : launch<AK, BKK, 128, 128, 2, 2, 16, 1>(d, ws, ws_bytes, stream);           \
+  if (g_variant == 1) return launch<AK, BKK, 64, 128, 2, 2>(d, ws, ws_bytes, stream);        \
+  if (g_variant == 2) return launch<AK, BKK, 128, 64, 2, 2>(d, ws, ws_bytes, stream);        \
+  if (g_variant == 3) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);         \
+  if (g_variant == 4) return launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream);       \
+  if (g_variant == 5) return launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream);        \
   return half ? launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream)                      \
               : launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream)
   if (!d.a_kmajor && !d.b_kmajor) { GEMM_PICK(0, 0); }

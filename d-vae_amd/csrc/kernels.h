@@ -45,6 +45,12 @@ int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, 
 int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st);
 int k_gm_bn_fwd(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C,
                 const float* WgmT, const float* bgm, int HP, hipStream_t st);
+// fused level steps (level.hip): hidden GEMM + GRU gates for prefix/node rows [p0,p1) whose
+// h_in is in AGG; gate/map GEMM + sigmoid(g)*m for node rows [ns,ne)
+int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+                    const GruW& w, int HP, int prio, hipStream_t st);
+int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
+                   int HP, int prio, hipStream_t st);
 // with_gm_grad=0 (mod bn): only gathers dGM into GMP[:, :HP] scaled for the weight grads
 int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st);

@@ -239,11 +239,40 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
   }
 }
 
+// tmp[g*len + k] = sum of partials [g*fold, (g+1)*fold) at k; same 4-way interleave as above
+__global__ __launch_bounds__(256) void reduce_groups_kernel(const float* __restrict__ part, int nparts, size_t stride,
+                                                            int fold, float* __restrict__ tmp, size_t len) {
+  __shared__ float sh[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t k = (size_t)blockIdx.x * 64 + col;
+  const int c0 = blockIdx.y * fold, c1 = min(nparts, c0 + fold);
+  float s = 0.f;
+  if (k < len)
+    for (int c = c0 + grp; c < c1; c += 4) s += part[c * stride + k];
+  sh[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && k < len) tmp[(size_t)blockIdx.y * len + k] = (sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col]);
+}
+
 int reduce_parts(const float* part, int nparts, size_t stride, float* out, size_t len, hipStream_t st) {
   const int grid = (int)std::min<size_t>((len + 63) / 64, 4096);
   hipLaunchKernelGGL(reduce_parts_kernel, dim3(grid), dim3(256), 0, st, part, nparts, stride, out, len);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
+}
+
+// Same sum in two fixed-order stages for a SHORT vector with MANY partials (pair_bwd_a's
+// dw2: 2052 floats x 2048 waves): stage 1 folds groups of `fold` consecutive partials into
+// the head of the partial buffer's own tail-free scratch `tmp`, stage 2 sums the groups.
+int reduce_parts_2stage(const float* part, int nparts, size_t stride, float* tmp, size_t tmp_floats, float* out,
+                        size_t len, hipStream_t st) {
+  const int fold = 32;
+  const int groups = cdiv(nparts, fold);
+  if (nparts <= 64 || (size_t)groups * len > tmp_floats) return reduce_parts(part, nparts, stride, out, len, st);
+  const int gx = (int)((len + 63) / 64);
+  hipLaunchKernelGGL(reduce_groups_kernel, dim3(gx, groups), dim3(256), 0, st, part, nparts, stride, fold, tmp, len);
+  DVAE_LAUNCH_CHECK();
+  return reduce_parts(tmp, groups, len, out, len, st);
 }
 
 // one-hot side tables for the skinny weight gradients (TN GEMMs):
@@ -851,7 +880,9 @@ int k_pair_bwd_a(const SchedView& sv, int R, int RH, const float* A, const float
   VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_a_kernel<V>), dim3(grid), dim3(256), 0, st, sv, R, RH, A, Bq, Cq,
                                        w2, d_edge, DA, part));
   DVAE_LAUNCH_CHECK();
-  return reduce_parts(part, grid * 4, per, out, per, st);
+  // the scratch behind the per-wave partials holds the group sums of the two-stage reduction
+  const size_t used = (size_t)grid * 4 * per;
+  return reduce_parts_2stage(part, grid * 4, per, part + used, part_floats - used, out, per, st);
 }
 
 int k_pair_bwd_b(const SchedView& sv, int R, const int* sizes, const float* A, const float* Bq,

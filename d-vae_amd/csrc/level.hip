@@ -1,0 +1,278 @@
+// Fused level-step kernels (forward): one launch does the dense contraction of a
+// level on the fp32 matrix cores AND the gate arithmetic that consumes it.
+//
+//   level_gru:  GH = h_in . Whh^T  ->  GRUCell gates r,z,n and the new state
+//               (dvae_model.py:83,244), replacing "hidden GEMM + gru_fwd_kernel"
+//   level_gm :  GMP = h . [Wg;Wm][:, :H]^T  ->  sigmoid(g) * m with the position
+//               columns and biases folded in as posb (dvae_model.py:71-79),
+//               replacing "gate/map GEMM + gm_fwd_kernel"
+//
+// The weight matrices keep their layout (gates stacked at multiples of HP rows).
+// A workgroup takes 64 hidden units and loads the matching 64 rows of EVERY gate
+// into its LDS tile, so that after the k loop each lane holds all G pre-activations
+// of the same (row, hidden unit) and the epilogue needs no second pass over HBM.
+// Same MFMA (v_mfma_f32_32x32x2_f32), same k order and the same gate formulas as
+// gemm.hip + kernels.hip: results are bitwise those of the unfused path.
+#include "kernels.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDM = BK + 4;
+constexpr int BNG = 64;   // hidden units per workgroup
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
+  return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int x = bid & 7, j = bid >> 3;
+  const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + j;
+}
+
+struct LevelCore {
+  const float* A; int lda; int M;   // [M][K] rows of this launch
+  const float* W; int ldw;          // [G*HP][K]
+  int K, HP;
+  int tiles_n, nblk;
+  int prio;
+};
+
+struct GruEpi {
+  SchedDir S; int R, prefix, p_base;
+  const float* x; int N, C;
+  GruW w;
+  const float* AGG; float* GH; float* GHN; float* HV; float* Hn;
+};
+
+struct GmEpi {
+  SchedDir S; int r_base;
+  const float* posb; float* GMP; float* GM;
+};
+
+// per-row state of the GRU epilogue: the node encoding is almost always one-hot, in which
+// case the input product x.W_ih^T is ONE row of WihT (same fmaf as the general loop, so the
+// same bits) and the epilogue has no divergent loop
+struct GruRow { int p, r; const float* xr; int hot; float xv; bool fin; };
+
+// row m of the launch, hidden units [col, col+4): v[g] = the G pre-activations
+__device__ __forceinline__ void epilogue(const GruEpi& e, int HP, const GruRow& rw, int col, const float4* v) {
+  float4 gi[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) gi[g] = ld4(e.w.bih + g * HP + col);
+  if (rw.hot >= 0) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gi[g] = fma4(rw.xv, ld4(e.w.WihT + (size_t)rw.hot * 3 * HP + g * HP + col), gi[g]);
+  } else if (rw.hot == -2) {
+    for (int c = 0; c < e.C; ++c) {
+      const float xv = rw.xr[c];
+      if (xv != 0.f) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gi[g] = fma4(xv, ld4(e.w.WihT + (size_t)c * 3 * HP + g * HP + col), gi[g]);
+      }
+    }
+  }
+  const float4 ghr = add4(ld4(e.w.bhh + col), v[0]);
+  const float4 ghz = add4(ld4(e.w.bhh + HP + col), v[1]);
+  const float4 ghn = add4(ld4(e.w.bhh + 2 * HP + col), v[2]);
+  const float4 a = ld4(e.AGG + (size_t)rw.p * HP + col);
+  float4 rr, zz, nn, hh;
+#define GRU_LANE(f)                                   \
+  rr.f = sigm(gi[0].f + ghr.f);                       \
+  zz.f = sigm(gi[1].f + ghz.f);                       \
+  nn.f = tanhf(gi[2].f + rr.f * ghn.f);               \
+  hh.f = (1.f - zz.f) * nn.f + zz.f * a.f;
+  GRU_LANE(x) GRU_LANE(y) GRU_LANE(z) GRU_LANE(w)
+#undef GRU_LANE
+  float* gh = e.GH + (size_t)rw.p * 3 * HP;
+  st4(gh + col, rr);
+  st4(gh + HP + col, zz);
+  st4(gh + 2 * HP + col, nn);
+  st4(e.GHN + (size_t)rw.p * HP + col, ghn);
+  st4(e.HV + (size_t)rw.p * HP + col, hh);
+  if (rw.fin) st4(e.Hn + (size_t)rw.r * HP + col, hh);
+}
+
+struct GmRow { int r; const float* pb; };
+
+__device__ __forceinline__ void epilogue(const GmEpi& e, int HP, const GmRow& rw, int col, const float4* v) {
+  const float4 gpre = add4(v[0], ld4(rw.pb + col));
+  const float4 mm = add4(v[1], ld4(rw.pb + HP + col));
+  const float4 g = make_float4(sigm(gpre.x), sigm(gpre.y), sigm(gpre.z), sigm(gpre.w));
+  float* gp = e.GMP + (size_t)rw.r * 2 * HP;
+  st4(gp + col, g);
+  st4(gp + HP + col, mm);
+  st4(e.GM + (size_t)rw.r * HP + col, make_float4(g.x * mm.x, g.y * mm.y, g.z * mm.z, g.w * mm.w));
+}
+
+__device__ __forceinline__ GruRow row_meta(const GruEpi& e, int HP, int m) {
+  GruRow rw;
+  rw.p = e.p_base + m;
+  rw.r = e.prefix ? e.S.prow_node[rw.p] : rw.p;
+  rw.xr = e.x + ((size_t)e.S.row_graph[rw.r] * e.N + e.S.row_node[rw.r]) * e.C;
+  rw.fin = e.prefix && rw.p == final_prow(e.S, e.R, rw.r);
+  // hot = c if x has exactly one nonzero (at c), -1 if x is all zero, -2 otherwise
+  rw.hot = -1; rw.xv = 0.f;
+  for (int c = 0; c < e.C; ++c) {
+    const float xv = rw.xr[c];
+    if (xv != 0.f) { rw.hot = rw.hot == -1 ? c : -2; rw.xv = xv; }
+  }
+  return rw;
+}
+__device__ __forceinline__ GmRow row_meta(const GmEpi& e, int HP, int m) {
+  GmRow rw;
+  rw.r = e.r_base + m;
+  rw.pb = e.posb + (size_t)e.S.row_node[rw.r] * 2 * HP;
+  return rw;
+}
+
+// G gates, TM row sub-tiles per wave: workgroup tile = (64*TM) rows x (G x 64) columns,
+// four waves as 2 (rows) x 2 (hidden units), each wave TM x G MFMA tiles of 32x32.
+template <int G, int TM, class Epi>
+__global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
+  constexpr int BM = 64 * TM;
+  constexpr int A_FLOATS = BM * LDM, B_FLOATS = G * BNG * LDM;
+  constexpr int NVA = BM * BK / 4 / 256, NVB = G * BNG * BK / 4 / 256;   // float4 per thread
+  __shared__ __attribute__((aligned(16))) float lds[A_FLOATS + B_FLOATS];
+  float* As = lds;
+  float* Bs = lds + A_FLOATS;
+
+  if (p.prio) __builtin_amdgcn_s_setprio(2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, p.nblk);
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BNG;
+
+  f32x16 acc[TM][G];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.f;
+
+  // one tile row = 8 float4; thread t covers row t/8 (+32 per step), quad t%8.  Rows beyond M
+  // are clamped to the last row (their results are never stored); K and HP are multiples of
+  // the tile sizes, so no load needs a predicate.
+  const int lr = tid >> 3, kq = (tid & 7) * 4;
+  const float* pa[NVA];
+  const float* pb[NVB];
+#pragma unroll
+  for (int i = 0; i < NVA; ++i) pa[i] = p.A + (size_t)min(m0 + lr + 32 * i, p.M - 1) * p.lda + kq;
+#pragma unroll
+  for (int i = 0; i < NVB; ++i) pb[i] = p.W + ((size_t)(i >> 1) * p.HP + n0 + lr + 32 * (i & 1)) * p.ldw + kq;
+  float4 va[NVA], vb[NVB];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) va[i] = ld4(pa[i] + k0);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) vb[i] = ld4(pb[i] + k0);
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) st4(As + (lr + 32 * i) * LDM + kq, va[i]);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) st4(Bs + (lr + 32 * i) * LDM + kq, vb[i]);
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      float4 af[TM], bf[G];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = ld4(As + (wm * (BM / 2) + i * 32 + (lane & 31)) * LDM + kc * 8 + (lane >> 5) * 4);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        bf[g] = ld4(Bs + (g * BNG + wn * 32 + (lane & 31)) * LDM + kc * 8 + (lane >> 5) * 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          // n-operand first: the accumulator holds C^T, each lane owns runs of 4 hidden units
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].x, af[i].x, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].y, af[i].y, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].z, af[i].z, acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].w, af[i].w, acc[i][g], 0, 0, 0);
+        }
+    }
+  };
+
+  load(0);
+  store();
+  __syncthreads();
+  int k0 = 0;
+  for (; k0 + BK < p.K; k0 += BK) {
+    load(k0 + BK);
+    compute();
+    __syncthreads();
+    store();
+    __syncthreads();
+  }
+  compute();
+
+  // epilogue: lane owns row m = lane&31 of each row sub-tile and, per register group q,
+  // hidden units n0 + 32*wn + 8q + 4*(lane>>5) + 0..3 of every gate
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    const auto rw = row_meta(e, p.HP, m);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = n0 + wn * 32 + 8 * q + 4 * (lane >> 5);
+      float4 v[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        v[g] = make_float4(acc[i][g][4 * q], acc[i][g][4 * q + 1], acc[i][g][4 * q + 2], acc[i][g][4 * q + 3]);
+      epilogue(e, p.HP, rw, col, v);
+    }
+  }
+}
+
+template <int G, class Epi>
+int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
+  c.tiles_n = c.HP / BNG;
+  const bool big = (long long)cdiv(c.M, 128) * c.tiles_n >= 512;
+  void* pr = gemm_prof_begin(2.0 * c.M * G * c.HP * (double)c.K, st);
+  if (big) {
+    c.nblk = cdiv(c.M, 128) * c.tiles_n;
+    hipLaunchKernelGGL((level_kernel<G, 2, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+  } else {
+    c.nblk = cdiv(c.M, 64) * c.tiles_n;
+    hipLaunchKernelGGL((level_kernel<G, 1, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+  }
+  gemm_prof_end(pr, st);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+}  // namespace
+
+int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+                    const GruW& w, int HP, int prio, hipStream_t st) {
+  if (p1 <= p0) return DVAE_OK;
+  DVAE_REQUIRE(HP % BNG == 0 && HP % BK == 0, "level_gru: HP must be a multiple of 64");
+  LevelCore c{};
+  c.A = b.AGG + (size_t)p0 * HP; c.lda = HP; c.M = p1 - p0;
+  c.W = w.Whh; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
+  GruEpi e{S, b.R, b.prefix, p0, x, N, C, w, b.AGG, b.GH, b.GHN, b.HV, b.Hn};
+  return launch_level<3>(c, e, st);
+}
+
+int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
+                   int HP, int prio, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  DVAE_REQUIRE(HP % BNG == 0 && HP % BK == 0, "level_gm: HP must be a multiple of 64");
+  LevelCore c{};
+  c.A = b.Hn + (size_t)ns * HP; c.lda = HP; c.M = ne - ns;
+  c.W = Wgm; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
+  GmEpi e{S, ns, posb, b.GMP, b.GM};
+  return launch_level<2>(c, e, st);
+}

@@ -7,6 +7,8 @@ lib = _lib.load()
 dev = torch.device('cuda')
 ws = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
 shapes = [  # (layout, M, N, K)
+    ('nt', 2048, 1536, 512), ('nt', 2048, 1024, 512), ('nn', 2048, 512, 1536), ('nn', 2048, 512, 1024),
+    ('nt', 512, 1536, 512), ('nn', 512, 512, 1536),
     ('nt', 4096, 1536, 512), ('nt', 4096, 1024, 512), ('nt', 8192, 1536, 512), ('nt', 90000, 2048, 512),
     ('nt', 32768, 2048, 512), ('nt', 32768, 1024, 512),
     ('nn', 4096, 512, 1536), ('nn', 4096, 512, 1024), ('nn', 8192, 512, 1536), ('nn', 90000, 512, 2048),
@@ -22,8 +24,8 @@ for lay, M, N, K in shapes:
         A = torch.randn(K, M, device=dev); B = torch.randn(K, N, device=dev); akm, bkm = 1, 1
     C = torch.empty(M, N, device=dev)
     line = '%s M=%6d N=%5d K=%6d ' % (lay, M, N, K)
-    for mode in (0, 1, 2, 3):
-        lib.dvae_gemm_dbg(mode)
+    for mode in (5, 1, 2, 3, 4):
+        lib.dvae_gemm_variant(mode)
         def run():
             E.check(lib.dvae_gemm_f32(E._ptr(A), A.stride(0), akm, E._ptr(B), B.stride(0), bkm, E._ptr(C), N, M, N, K,
                                       None, 0, 0, E._ptr(ws), ws.numel(), E._stream()))
@@ -38,4 +40,4 @@ for lay, M, N, K in shapes:
         us = best
         line += ' | v%d %7.1f us %5.1f TF' % (mode, us, 2.0 * M * N * K / us / 1e6)
     print(line, flush=True)
-lib.dvae_gemm_dbg(0)
+lib.dvae_gemm_variant(0)
