@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=4096)
     ap.add_argument("--per-gpu-batch", type=int, default=0, help="weak scaling: fixed batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="build each schedule at the start of its own step")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
 
@@ -122,8 +123,16 @@ def main():
 
     sync_grads = dp.make_grad_sync(dist, force=force_dist)       # SUM all-reduce: the losses are sums (dvae_model.py:405)
 
+    # the level schedule of batch i+1 is queued (own stream) as soon as step i has been
+    # launched, as a prefetching data loader would: every step still builds one schedule
+    # inside the timed region, but nobody waits for its host round trip
+    prepared = {}
+
     def step(i):
-        out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads)
+        sched = prepared.pop(i, None)
+        out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads, sched=sched)
+        if not args.no_prefetch:
+            prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True)
         opt.step()
         return out4
 

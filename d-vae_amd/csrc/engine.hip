@@ -169,17 +169,17 @@ thread_local Events g_events;
 
 // ---- GEMM shorthands ---------------------------------------------------------
 struct G {
-  float* ws; hipStream_t st; int prio = 0;
+  float* ws; hipStream_t st; int prio = 0; int bulk = 0;
   // Y[M][N] (+)= X[M][K] W[N][K]^T + bias
   int nt(const float* X, int ldx, const float* W, int ldw, float* Y, int ldy, int M, int N, int K,
          const float* bias = nullptr, int relu = 0, int acc = 0) const {
-    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio};
+    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio, bulk};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dX[M][N] (+)= dY[M][K] W[K][N]
   int nn(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K,
          int acc = 0) const {
-    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio};
+    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio, bulk};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dW[M][N] (+)= dY[K][M]^T X[K][N]   (K = rows)
@@ -193,7 +193,7 @@ struct G {
       }
       return DVAE_OK;
     }
-    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc, prio};
+    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc, prio, bulk};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
 };
@@ -484,7 +484,7 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
   EncWs w = enc_ws(d, lf.R, lf.E, ws);
   const EncLayout L = enc_layout(d);
   const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
-  const G gs{w.sc[1].gemm_ws, sd};       // weight-gradient products
+  const G gs{w.sc[1].gemm_ws, sd, 0, sd != st ? 1 : 0};       // weight-gradient products
   const Scratch& ssc = w.sc[1];
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, ZP = d.ZP;
@@ -560,7 +560,7 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
   DecWs w = dec_ws(d, lv.R, lv.E, ws);
   const DecLayout L = dec_layout(d);
   const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
-  const G gs{w.sc[1].gemm_ws, sd};
+  const G gs{w.sc[1].gemm_ws, sd, 0, sd != st ? 1 : 0};
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, R = lv.R, EHP = d.EHP;
 
@@ -619,7 +619,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DecWs w = dec_ws(d, lv.R, lv.E, ws);
   const DecLayout L = dec_layout(d);
   const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
-  const G gs{w.sc[1].gemm_ws, sd};       // weight-gradient products
+  const G gs{w.sc[1].gemm_ws, sd, 0, sd != st ? 1 : 0};       // weight-gradient products
   const Scratch& msc = w.sc[0];
   const Scratch& ssc = w.sc[1];
   Events& ev = g_events;

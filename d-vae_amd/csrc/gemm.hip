@@ -20,6 +20,7 @@
 // The k order inside an 8-wide chunk is permuted (lane half h owns k = 4h..4h+3)
 // consistently for A and B, which only reorders the fp32 summation.
 #include <algorithm>
+#include <cstdlib>
 #include <deque>
 #include <mutex>
 #include <utility>
@@ -372,7 +373,8 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   // weight-gradient products: small [out][in] result, reduction over all rows)
   int splits = 1;
   if (p.nblk < 256 && d.K >= 2048 && ws) {
-    splits = min(cdiv(g_splitk_blocks, p.nblk), d.K / 512);
+    static const int bulk_blocks = getenv("DVAE_BULK_BLOCKS") ? atoi(getenv("DVAE_BULK_BLOCKS")) : 768;   // tuning
+    splits = min(cdiv(d.bulk ? bulk_blocks : g_splitk_blocks, p.nblk), d.K / 512);
   } else if (p.nblk <= 128 && d.K >= 512 && ws) {
     // small-batch per-level products: a handful of tiles, each walking the whole K
     // loop at one workgroup per CU, is latency-bound -- spread K over the idle CUs
@@ -439,7 +441,7 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   else if (!narrow) {
     const long long t128 = (long long)cdiv(d.M, 128) * cdiv(d.N, 128);
     const long long t64 = (long long)cdiv(d.M, 64) * cdiv(d.N, 128);
-    const bool splitk = d.K >= 2048 && t128 < 256 && ws;
+    const bool splitk = d.K >= 8192 && t128 < 256 && ws;   // weight gradients: reduction over all rows
     if (!splitk) {
       const long long c128 = ((t128 + 255) / 256) * 2, c64 = (t64 + 255) / 256;
       if (t128 >= 512) half = c64 < c128 && t128 < 2048;
@@ -450,8 +452,8 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
 #define GEMM_PICK(AK, BKK)                                                                   \
   if (narrow) return launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream);                \
   if (quarter) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);                \
-  if (g_variant == 1) return launch<AK, BKK, 64, 128, 2, 2>(d, ws, ws_bytes, stream);        \
-  if (g_variant == 2) return launch<AK, BKK, 128, 64, 2, 2>(d, ws, ws_bytes, stream);        \
+  if (g_variant == 1) return launch<AK, BKK, 64, 64, 2, 2, 128, 1>(d, ws, ws_bytes, stream); \
+  if (g_variant == 2) return launch<AK, BKK, 64, 64, 2, 2, 64, 1>(d, ws, ws_bytes, stream);  \
   if (g_variant == 3) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);         \
   if (g_variant == 4) return launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream);       \
   if (g_variant == 5) return launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream);        \
@@ -473,7 +475,7 @@ extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float*
   d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
   d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
   d.bias = bias; d.relu = relu; d.accumulate = accumulate;
-  d.prio = 0;
+  d.prio = 0; d.bulk = 0;
   return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -91,16 +91,30 @@ def _f32c(t):
 _pinned = {}
 
 
+def _pinned_info(dev_index, nint):
+    """Small ring of pinned host buffers for schedule summaries (a schedule built ahead of
+    time must not share its buffer with the one in use)."""
+    key = (dev_index, nint)
+    ring = _pinned.setdefault(key, [[], 0])
+    if len(ring[0]) < 8:
+        ring[0].append(torch.empty(nint, dtype=torch.int32).pin_memory())
+        return ring[0][-1]
+    ring[1] = (ring[1] + 1) % len(ring[0])
+    return ring[0][ring[1]]
+
+
 class Schedule:
     """Topological-level schedule of a batch of DAGs (device) + its host summary.
 
     g [B,N,N] fp32 0/1 strictly lower-triangular, g[b,i,j]=1 <=> edge j->i
     (reference layout, dataloader.py:75-86); sizes optional int32 [B].
-    Building it costs one stream synchronisation (level row counts are needed on
-    the host to size the per-level GEMMs).
+    The per-level row counts are needed on the host to size the per-level
+    GEMMs, so a schedule costs one wait for its build kernels.  With
+    ``defer=True`` (``Dvae.prepare``) the build is queued on ``stream`` and the
+    wait happens on first use -- built one batch ahead, it costs nothing.
     """
 
-    def __init__(self, g, sizes=None, want_reverse=False):
+    def __init__(self, g, sizes=None, want_reverse=False, stream=None, defer=False):
         _require_cuda(g, "X['graph']")
         assert g.dim() == 3 and g.shape[1] == g.shape[2], "graph must be [B,N,N]"
         lib = load()
@@ -108,23 +122,57 @@ class Schedule:
         self.B, self.N = int(g.shape[0]), int(g.shape[1])
         self.sizes = None if sizes is None else sizes.detach().to(device=g.device, dtype=torch.int32).contiguous()
         self.want_reverse = bool(want_reverse)
-        nbytes = lib.dvae_sched_bytes(self.B, self.N)
-        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
-        nint = _lib.sched_info_ints(self.N)
-        key = (g.device.index, nint)
-        if key not in _pinned:
-            _pinned[key] = torch.empty(nint, dtype=torch.int32).pin_memory()
-        pin = _pinned[key]
-        check(lib.dvae_sched_build(_ptr(self.g), _ptr(self.sizes), self.B, self.N, int(self.want_reverse),
-                                   _ptr(self.buf), ctypes.c_void_p(pin.data_ptr()), _stream()))
-        torch.cuda.current_stream().synchronize()
-        self.info = pin.numpy().copy()
-        if self.info[0] != 0:
-            raise _lib.GraphError(
-                "X['graph'] must be a 0/1 strictly lower-triangular adjacency "
-                "(node index order = topological order) within each graph's size")
-        self.R, self.E = int(self.info[1]), int(self.info[2])
-        self.nlev_fwd, self.nlev_rev = int(self.info[3]), int(self.info[4])
+        self.stream = stream if stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(self.stream):
+            nbytes = lib.dvae_sched_bytes(self.B, self.N)
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+            self._pin = _pinned_info(g.device.index, _lib.sched_info_ints(self.N))
+            check(lib.dvae_sched_build(_ptr(self.g), _ptr(self.sizes), self.B, self.N, int(self.want_reverse),
+                                       _ptr(self.buf), ctypes.c_void_p(self._pin.data_ptr()),
+                                       ctypes.c_void_p(self.stream.cuda_stream)))
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+        self._info = None
+        if not defer:
+            self.wait()
+
+    def wait(self):
+        """Host wait for the build (first call only); validates the adjacency."""
+        if self._info is None:
+            self.event.synchronize()
+            self._info = self._pin.numpy().copy()
+            self._pin = None
+            if self._info[0] != 0:
+                raise _lib.GraphError(
+                    "X['graph'] must be a 0/1 strictly lower-triangular adjacency "
+                    "(node index order = topological order) within each graph's size")
+        return self
+
+    def join(self, stream):
+        """Order `stream` after the build (no-op on the build's own stream)."""
+        if stream != self.stream:
+            stream.wait_event(self.event)
+            self.buf.record_stream(stream)
+
+    @property
+    def info(self):
+        return self.wait()._info
+
+    @property
+    def R(self):
+        return int(self.info[1])
+
+    @property
+    def E(self):
+        return int(self.info[2])
+
+    @property
+    def nlev_fwd(self):
+        return int(self.info[3])
+
+    @property
+    def nlev_rev(self):
+        return int(self.info[4])
 
     @property
     def info_ptr(self):

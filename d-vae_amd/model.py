@@ -212,6 +212,7 @@ class Dvae(nn.Module):
         self.beta = getattr(hparams, 'beta', 0.005)
         self._flat = None
         self._side = None
+        self._prep = None
 
     # -- reference API -------------------------------------------------------
     def reparamterize(self, mu, logvar, eps=None):
@@ -328,7 +329,20 @@ class Dvae(nn.Module):
         ec.backward(None, gmu, glv, Ge, side=side)
         return out4, Gd, Ge, (ec, dc)
 
-    def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, micro_batches=None):
+    def prepare(self, batch, resident=False):
+        """Queue the level-schedule build of a FUTURE batch on a stream of its own and
+        return at once; pass the result to ``loss_and_grad(batch, sched=...)``.  A data
+        loader that calls this one batch ahead hides the schedule's host round trip
+        (its build kernels run beside the previous step when ``resident``)."""
+        g, _, sizes = _batch_parts(batch)
+        dev = g.device
+        if self._prep is None or self._prep.device != dev:
+            self._prep = torch.cuda.Stream(device=dev)
+        if not resident:   # resident=True: the batch tensors are complete already, start at once
+            self._prep.wait_stream(torch.cuda.current_stream())
+        return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, stream=self._prep, defer=True)
+
+    def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, micro_batches=None, sched=None):
         """Forward + backward of training_step's loss without building an autograd
         graph: same kernels, gradients written straight into flat buffers whose
         views become ``p.grad``.  ``grad_sync(flat)`` (optional) is called as soon
@@ -361,8 +375,14 @@ class Dvae(nn.Module):
                 part = (g[lo:hi], x[lo:hi], None if sizes is None else sizes[lo:hi])
                 parts.append(part)
             # all level schedules first: building one costs a host sync
-            for part in parts:
-                scheds.append(E.Schedule(part[0], part[2], want_reverse=enc.is_bidirectional))
+            if sched is not None:
+                assert nmb == 1 and sched.B == B and sched.N == int(g.shape[1]), \
+                    "sched was prepared for another batch"
+                sched.join(main)
+                scheds.append(sched.wait())
+            else:
+                for part in parts:
+                    scheds.append(E.Schedule(part[0], part[2], want_reverse=enc.is_bidirectional))
             d_enc = [E._dims_for(enc._dims, sc.B, sc.N) for sc in scheds]
             d_dec = [E._dims_for(dec._dims, sc.B, sc.N) for sc in scheds]
             Pe = enc._pack.pack(d_enc[0], enc_p)
