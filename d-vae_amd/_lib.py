@@ -53,6 +53,9 @@ SIGNATURES = {
                               c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dvae_gemm_force_tile": (c_int, [c_int]),
     "dvae_gemm_tune": (c_int, [c_int, c_int]),
+    "dvae_gemm_variant": (c_int, [c_int]),
+    "dvae_gemm_dbg": (c_int, [c_int]),
+    "dvae_level_tune": (c_int, [c_int, c_int]),
     "dvae_gemm_profile": (c_int, [c_int]),
     "dvae_gemm_profile_read": (c_int, [c_void_p]),
     "dvae_sched_bytes": (c_size_t, [c_int, c_int]),

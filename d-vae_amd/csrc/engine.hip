@@ -17,6 +17,15 @@
 
 namespace {
 
+struct LevelCfg {
+  int fused_gm_min_rows; int fused_gru;
+  LevelCfg() {
+    fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : 2048;
+    fused_gru = (!getenv("DVAE_UNFUSED") && getenv("DVAE_FUSED_GRU")) ? 1 : 0;
+  }
+};
+LevelCfg g_level_cfg;
+
 struct Carver {
   char* base; size_t off;
   float* f(size_t n) {
@@ -239,13 +248,14 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
   const int z1 = lv.nlev > 0 ? lv.ls[1] : R;   // end of level 0
-  // Fused level steps (level.hip).  The gate/map step is fused by default (one launch, 25 %
-  // less time than GEMM + epilogue kernel).  The fused GRU step is parity-green but measured
-  // slower than "64x128-tile GEMM + gru_fwd_kernel" on MI355X (a workgroup must hold all three
-  // gates of its hidden units, which leaves 2 instead of 3 waves per SIMD): opt-in with
-  // DVAE_FUSED_GRU=1.  DVAE_UNFUSED=1 turns both off (A-B tests).
-  static const bool unfused = getenv("DVAE_UNFUSED") != nullptr;
-  static const bool fused_gru = !unfused && getenv("DVAE_FUSED_GRU") != nullptr;
+  // Fused level steps (level.hip).  The gate/map step is fused by default from 2048 rows up
+  // (one launch, 25 % less time than GEMM + epilogue kernel; below that the fused tile grid
+  // is too small to fill the chip).  The fused GRU step is parity-green but measured slower
+  // than "64x128-tile GEMM + gru_fwd_kernel" on MI355X (a workgroup must hold all three
+  // gates of its hidden units, which leaves 2 instead of 3 waves per SIMD): opt-in through
+  // dvae_level_tune / DVAE_FUSED_GRU=1.
+  const bool fused_gru = g_level_cfg.fused_gru != 0;
+  const int fused_gm_min = g_level_cfg.fused_gm_min_rows;
   auto gru_rows = [&](int p0, int p1) -> int {
     if (fused_gru) return k_level_gru_fwd(S, p0, p1, b, x, d.N, d.C, w.gru, HP, g.prio, st);
     DVAE_TRY(g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0, 3 * HP, HP));
@@ -283,7 +293,7 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     }
     if (hook) DVAE_TRY(hook(p0, p1, ns, ne));
     if (L + 1 < lv.nlev) {   // nodes of the last level have no successors
-      if (!unfused && ne - ns >= 2048) {   // below that the fused tile grid is too small to fill the chip
+      if (fused_gm_min >= 0 && ne - ns >= fused_gm_min) {
         DVAE_TRY(k_level_gm_fwd(S, ns, ne, b, w.gm, w.gm + (size_t)2 * HP * HP, HP, g.prio, st));
       } else {
         DVAE_TRY(g.nt(b.Hn + (size_t)ns * HP, HP, w.gm, HP, b.GMP + (size_t)ns * 2 * HP, 2 * HP, ne - ns, 2 * HP,
@@ -719,5 +729,13 @@ extern "C" int dvae_side_stream_create(void** stream_out, int* priority_out) {
 
 extern "C" int dvae_side_stream_destroy(void* stream) {
   if (stream) DVAE_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return DVAE_OK;
+}
+
+// tuning / test knob: rows from which the gate/map step runs fused (-1 never, 0 always),
+// and whether the GRU step runs fused
+extern "C" int dvae_level_tune(int fused_gm_min_rows, int fused_gru) {
+  g_level_cfg.fused_gm_min_rows = fused_gm_min_rows;
+  g_level_cfg.fused_gru = fused_gru;
   return DVAE_OK;
 }

@@ -11,8 +11,8 @@
 // A workgroup takes 64 hidden units and loads the matching 64 rows of EVERY gate
 // into its LDS tile, so that after the k loop each lane holds all G pre-activations
 // of the same (row, hidden unit) and the epilogue needs no second pass over HBM.
-// Same MFMA (v_mfma_f32_32x32x2_f32), same k order and the same gate formulas as
-// gemm.hip + kernels.hip: results are bitwise those of the unfused path.
+// Same MFMA (v_mfma_f32_32x32x2_f32) and the same gate formulas as gemm.hip +
+// kernels.hip; the fp32 summation order differs only where the plain GEMM splits K.
 #include "kernels.h"
 
 namespace {

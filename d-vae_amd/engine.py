@@ -26,52 +26,20 @@ def _side(side):
 
 
 _side_streams = {}
-_mb_streams = {}
 
 
-def _new_side_stream(idx):
-    raw, prio = ctypes.c_void_p(), ctypes.c_int()
-    with torch.cuda.device(idx):
-        check(load().dvae_side_stream_create(ctypes.byref(raw), ctypes.byref(prio)))
-    return torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
-
-
-def side_stream(device, which=0):
-    """The library's low-priority side stream number `which` of `device` (created
-    once per process), wrapped as a torch stream so torch ops / RCCL can be
-    queued on it."""
+def side_stream(device):
+    """The library's low-priority side stream of `device` (one per device per
+    process), wrapped as a torch stream so torch ops / RCCL can be queued on it."""
     idx = torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
-    key = (idx, which)
-    if key not in _side_streams:
-        _side_streams[key] = _new_side_stream(idx)
-    return _side_streams[key]
-
-
-_pool = None
-
-
-def launch_pool():
-    """Host threads that feed the launch streams of the extra micro-batches."""
-    global _pool
-    if _pool is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _pool = ThreadPoolExecutor(max_workers=3, thread_name_prefix="dvae-launch")
-    return _pool
-
-
-def stream_pairs(device, n, main):
-    """(chain stream, side stream) for each of `n` concurrent micro-batches: the
-    first pair is (`main`, side 0), the others get a chain stream of their own."""
-    idx = torch.device(device).index
-    pairs = [(main, side_stream(device, 0))]
-    for i in range(1, n):
-        key = (idx, i)
-        if key not in _mb_streams:
-            _mb_streams[key] = torch.cuda.Stream(device=device)
-        pairs.append((_mb_streams[key], side_stream(device, i)))
-    return pairs
+    if idx not in _side_streams:
+        raw, prio = ctypes.c_void_p(), ctypes.c_int()
+        with torch.cuda.device(idx):
+            check(load().dvae_side_stream_create(ctypes.byref(raw), ctypes.byref(prio)))
+        _side_streams[idx] = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", idx))
+    return _side_streams[idx]
 
 
 def _require_cuda(t, name):

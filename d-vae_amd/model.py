@@ -306,29 +306,6 @@ class Dvae(nn.Module):
             self._flat = (key, fe, fd)
         return self._flat[1], self._flat[2]
 
-    def _half_step(self, part, eps, beta, d_enc, d_dec, Pe, Pd, sched, side):
-        """Forward + backward of one (micro-)batch on the current stream (+ `side`):
-        returns (out4, Gd, Ge) with the packed gradients possibly still being
-        written on `side`."""
-        enc, dec = self.encoder, self.decoder
-        g, x, sizes = part
-        xs = E._f32c(x)
-        ec = E.EncoderCall(d_enc, sched, xs, Pe)
-        if eps is None:
-            eps = torch.randn_like(ec.mu)
-        z = E.reparam_fwd(ec.mu, ec.logvar, eps)
-        dc = E.DecoderCall(d_dec, sched, z, xs, Pd, side=side)
-        out4, (ge, gt, gmu, glv) = E.elbo_call(d_dec, dc.edge_logits, dc.type_logits, sched.g, xs, sched.sizes,
-                                               ec.mu, ec.logvar, float(beta), True)
-        Gd = dec._pack.new_packed_grad()
-        Ge = enc._pack.new_packed_grad()
-        d_z = dc.backward(ge, gt, Gd, side=side)
-        dmu, dlv = E.reparam_bwd(d_z, ec.logvar, eps)
-        gmu.add_(dmu)
-        glv.add_(dlv)
-        ec.backward(None, gmu, glv, Ge, side=side)
-        return out4, Gd, Ge, (ec, dc)
-
     def prepare(self, batch, resident=False):
         """Queue the level-schedule build of a FUTURE batch on a stream of its own and
         return at once; pass the result to ``loss_and_grad(batch, sched=...)``.  A data
@@ -342,98 +319,61 @@ class Dvae(nn.Module):
             self._prep.wait_stream(torch.cuda.current_stream())
         return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, stream=self._prep, defer=True)
 
-    def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, micro_batches=None, sched=None):
+    def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, sched=None):
         """Forward + backward of training_step's loss without building an autograd
         graph: same kernels, gradients written straight into flat buffers whose
         views become ``p.grad``.  ``grad_sync(flat)`` (optional) is called as soon
         as a buffer is complete -- the decoder's while the encoder's backward is
-        still running -- and may return a handle with ``.wait()``.
-
-        ``micro_batches`` (default 1; 2 measured no faster on one MI355X): graphs are
-        independent and every loss is a sum, so the batch is cut into contiguous
-        micro-batches that run CONCURRENTLY on their own stream pairs; one
-        micro-batch's latency-bound level chains and bandwidth-bound pair kernels
-        fill with the other's bulk products.  Gradients are added in micro-batch
-        order (deterministic).
+        still running -- and may return a handle with ``.wait()``.  ``sched``: the
+        result of ``prepare(batch)`` for this batch (built ahead of time).
         Returns the device tensor [edge_loss, vertex_loss, kl_loss, loss]."""
         assert not self._shared_gm, "loss_and_grad does not support same_mapper_gater; use training_step"
         g, x, sizes = _batch_parts(batch)
         self.encoder._check(g, x)
         enc, dec = self.encoder, self.decoder
         enc_p, dec_p = enc.hip_params(), dec.hip_params()
-        B = int(g.shape[0])
-        if micro_batches is None:
-            micro_batches = 1
-        nmb = max(1, min(int(micro_batches), B))
         with torch.no_grad():
             main = torch.cuda.current_stream()
-            dev = main.device
-            bounds = [(B * i) // nmb for i in range(nmb + 1)]
-            parts, scheds = [], []
-            for i in range(nmb):
-                lo, hi = bounds[i], bounds[i + 1]
-                part = (g[lo:hi], x[lo:hi], None if sizes is None else sizes[lo:hi])
-                parts.append(part)
-            # all level schedules first: building one costs a host sync
             if sched is not None:
-                assert nmb == 1 and sched.B == B and sched.N == int(g.shape[1]), \
-                    "sched was prepared for another batch"
+                assert sched.B == int(g.shape[0]) and sched.N == int(g.shape[1]), "sched was prepared for another batch"
                 sched.join(main)
-                scheds.append(sched.wait())
+                sched.wait()
             else:
-                for part in parts:
-                    scheds.append(E.Schedule(part[0], part[2], want_reverse=enc.is_bidirectional))
-            d_enc = [E._dims_for(enc._dims, sc.B, sc.N) for sc in scheds]
-            d_dec = [E._dims_for(dec._dims, sc.B, sc.N) for sc in scheds]
-            Pe = enc._pack.pack(d_enc[0], enc_p)
-            Pd = dec._pack.pack(d_dec[0], dec_p)
+                sched = self._schedule(batch)
+            xs = E._f32c(x)
+            d_enc = E._dims_for(enc._dims, sched.B, sched.N)
+            d_dec = E._dims_for(dec._dims, sched.B, sched.N)
+            Pe = enc._pack.pack(d_enc, enc_p)
+            Pd = dec._pack.pack(d_dec, dec_p)
             fe, fd = self._flat_grads()
-            streams = E.stream_pairs(dev, nmb, main)
-            for mb_main, mb_side in streams:
-                if mb_main is not main:
-                    mb_main.wait_stream(main)
-                mb_side.wait_stream(mb_main)
-
-            def run(i):
-                # one host thread per micro-batch: the library calls release the GIL, so the
-                # launch streams of the micro-batches are fed in parallel
-                with torch.cuda.device(dev), torch.cuda.stream(streams[i][0]), torch.no_grad():
-                    e_i = None if eps is None else eps[bounds[i]:bounds[i + 1]]
-                    return self._half_step(parts[i], e_i, beta, d_enc[i], d_dec[i], Pe, Pd, scheds[i], streams[i][1])
-
-            if nmb == 1:
-                results = [run(0)]
-            else:
-                futures = [E.launch_pool().submit(run, i) for i in range(1, nmb)]
-                results = [run(0)] + [f.result() for f in futures]
-            # join: gradients summed in micro-batch order on the first side stream
-            side0 = streams[0][1]
-            out4, Gd, Ge, keep = results[0]
-            for i in range(1, nmb):
-                mb_main, mb_side = streams[i]
-                mb_main.wait_stream(mb_side)
-                side0.wait_stream(mb_main)
-                main.wait_stream(mb_main)
+            side = E.side_stream(main.device)
+            side.wait_stream(main)
             handles = []
-            with torch.cuda.stream(side0):
-                for i in range(1, nmb):
-                    Gd.add_(results[i][1])
+            ec = E.EncoderCall(d_enc, sched, xs, Pe)
+            if eps is None:
+                eps = torch.randn_like(ec.mu)
+            z = E.reparam_fwd(ec.mu, ec.logvar, eps)
+            dc = E.DecoderCall(d_dec, sched, z, xs, Pd, side=side)
+            out4, (ge, gt, gmu, glv) = E.elbo_call(d_dec, dc.edge_logits, dc.type_logits, sched.g, xs, sched.sizes,
+                                                   ec.mu, ec.logvar, float(beta), True)
+            Gd = dec._pack.new_packed_grad()
+            Ge = enc._pack.new_packed_grad()
+            # the weight-gradient products run on `side` beside the per-level chains; the
+            # decoder's unpack + all-reduce are queued there too, under the encoder's backward
+            d_z = dc.backward(ge, gt, Gd, side=side)
+            with torch.cuda.stream(side):
                 dec._pack.unpack(Gd, fd)
                 if grad_sync is not None:
                     handles.append(grad_sync(fd))
-                for i in range(1, nmb):
-                    Ge.add_(results[i][2])
+            dmu, dlv = E.reparam_bwd(d_z, ec.logvar, eps)
+            gmu.add_(dmu)
+            glv.add_(dlv)
+            ec.backward(None, gmu, glv, Ge, side=side)
+            with torch.cuda.stream(side):
                 enc._pack.unpack(Ge, fe)
                 if grad_sync is not None:
                     handles.append(grad_sync(fe))
-            for i in range(1, nmb):
-                out4 = out4 + results[i][0]
-            main.wait_stream(side0)
-            # memory handed out on the other streams is reused only after this step
-            for r in results[1:]:
-                for t in (r[0], r[1], r[2]):
-                    t.record_stream(main)
-                    t.record_stream(side0)
+            main.wait_stream(side)
             for p, v in zip(enc_p, enc._pack.views(fe, enc_p)):
                 p.grad = v
             for p, v in zip(dec_p, dec._pack.views(fd, dec_p)):

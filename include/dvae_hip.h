@@ -75,6 +75,8 @@ int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb
  * out12[6] (the unused layout slot) = wall milliseconds during which at least
  * one GEMM launch was running (launches on the two streams overlap). */
 int dvae_gemm_force_tile(int mode);   /* tuning knob: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
+int dvae_gemm_variant(int v);          /* lab knob: force a tile shape (0 = automatic) */
+int dvae_gemm_dbg(int bits);           /* lab knob: 1 skip the epilogue stores, 2 skip reloads (timing ablations) */
 int dvae_gemm_tune(int splitk_blocks, int force_prio);   /* tuning knobs: workgroups a split-K launch aims for
                                                            (0 = keep), wave priority override (-1 = caller's) */
 int dvae_gemm_profile(int enable);
@@ -187,6 +189,12 @@ int dvae_decoder_bwd(const dvae_dims* d, const float* z, const float* x, const i
                      const void* sched, const int* info_host, const float* P, void* ws,
                      const float* d_edge_logits, const float* d_type_logits, float* G, float* d_z,
                      void* stream, void* side_stream);
+
+/* Tuning / test knob of the forward level sweep (no counterpart in the reference): node rows
+ * per level from which the gate/map step runs as ONE fused launch (GEMM + sigmoid*map
+ * epilogue; -1 never, 0 always, default 2048) and whether the GRU step runs fused (hidden
+ * GEMM + gates in one launch; default 0).  Every combination computes the same formulas (fp32 summation order may differ). */
+int dvae_level_tune(int fused_gm_min_rows, int fused_gru);
 
 /* Side stream for the *_fwd / *_bwd calls above (no counterpart in the reference).
  * It is created with the LOWEST scheduling priority the device offers, so that the

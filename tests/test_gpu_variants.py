@@ -1,0 +1,76 @@
+"""GPU: the alternative execution forms of the train step give the results of the
+default form -- fused level kernels (same formulas; the only difference is that
+the plain GEMM may split K for small launches, i.e. fp32 summation order), a
+schedule built ahead of time (bitwise)."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from helpers import close_scaled, fill_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cuda, B, bidir=False, N=8, C=8, H=501, seed=3):
+    import dvae_amd
+    hp = Namespace(dataset_file=None, mod=None, bidirectional=bidir, num_classes=C, max_seq=N, hidden_state_size=H)
+    model = fill_weights(dvae_amd.Dvae(hp), seed).to(cuda)
+    g, x = dvae_amd.synth.random_dags(B, N, C, 0.35, seed=21, chain=True)
+    eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(4))
+    X = {'graph': g.to(cuda), 'node_encoding': x.to(cuda)}
+    return model, X, eps.to(cuda)
+
+
+def _step(model, X, eps, **kw):
+    model.zero_grad(set_to_none=True)
+    out4 = model.loss_and_grad(X, eps=eps, **kw)
+    return out4.clone(), torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+
+
+@pytest.mark.parametrize("bidir", [False, True])
+def test_fused_level_kernels(cuda, bidir):
+    """level.hip (hidden GEMM + GRU gates, gate/map GEMM + sigmoid*map in one launch each)
+    against the GEMM + epilogue-kernel form: same formulas, fp32 summation order may differ."""
+    from dvae_amd import _lib
+    lib = _lib.load()
+    model, X, eps = _setup(cuda, 96, bidir=bidir, H=501 if not bidir else 128)
+    try:
+        lib.dvae_level_tune(-1, 0)
+        ref = _step(model, X, eps)
+        with torch.no_grad():
+            ref_states = model.encoder.node_states(X)[0].clone()
+        for gm_min, gru in ((0, 0), (0, 1), (-1, 1)):
+            lib.dvae_level_tune(gm_min, gru)
+            out = _step(model, X, eps)
+            with torch.no_grad():
+                states = model.encoder.node_states(X)[0]
+            close_scaled(states, ref_states, tol=1e-5, what="states %d/%d" % (gm_min, gru))
+            close_scaled(out[0], ref[0], tol=1e-5, what="losses %d/%d" % (gm_min, gru))
+            # gradients: a 1e-7 change of a pre-activation can flip one ReLU of add_vertex /
+            # add_edge (a kink, not an error), which moves single entries by O(1e-2): L2 norm
+            rel = float((out[1] - ref[1]).norm() / ref[1].norm())
+            assert rel <= 1e-3, "gradients %d/%d: relative L2 error %.3e" % (gm_min, gru, rel)
+    finally:
+        lib.dvae_level_tune(2048, 0)
+
+
+def test_prepared_schedule_bitwise(cuda):
+    model, X, eps = _setup(cuda, 64)
+    ref = _step(model, X, eps)
+    sched = model.prepare(X)
+    out = _step(model, X, eps, sched=sched)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    sched = model.prepare(X, resident=True)
+    out = _step(model, X, eps, sched=sched)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+
+
+def test_prepared_schedule_rejects_bad_graph(cuda):
+    from dvae_amd import _lib
+    model, X, eps = _setup(cuda, 8)
+    bad = {k: v.clone() for k, v in X.items()}
+    bad['graph'][0, 2, 5] = 1.0          # edge from a later node: not lower-triangular
+    sched = model.prepare(bad)
+    with pytest.raises(_lib.GraphError):
+        model.loss_and_grad(bad, eps=eps, sched=sched)
