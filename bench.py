@@ -145,7 +145,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    prof = not args.no_profile
+    prof = not args.no_profile and world == 1      # per-launch HIP events: roofline figures are an N=1 report
     if prof:
         lib.dvae_gemm_profile(1)
     t0 = time.perf_counter()

@@ -32,7 +32,7 @@ static int g_splitk_blocks = 768;   // tuning knob: workgroups a split-K launch 
 static int g_force_prio = -1;       // tuning knob: -1 as requested by the caller, 0/1 override
 static int g_dbg = 0;
 extern "C" int dvae_gemm_dbg(int v) { g_dbg = v; return 0; }
-static int g_variant = 0;           // tuning knob: 0 BK32 1-stage, 1 BK16 2-stage, 2 BK32 2-stage, 3 BK16 1-stage
+static int g_variant = 0;           // lab knob: 0 default (BK16), 2 BK8 for 128x128, 3 BK32
 extern "C" int dvae_gemm_variant(int v) { g_variant = v; return 0; }
 
 namespace {
@@ -452,13 +452,14 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
 #define GEMM_PICK(AK, BKK)                                                                   \
   if (narrow) return launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream);                \
   if (quarter) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);                \
-  if (g_variant == 1) return launch<AK, BKK, 64, 64, 2, 2, 128, 1>(d, ws, ws_bytes, stream); \
-  if (g_variant == 2) return launch<AK, BKK, 64, 64, 2, 2, 64, 1>(d, ws, ws_bytes, stream);  \
-  if (g_variant == 3) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);         \
-  if (g_variant == 4) return launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream);       \
-  if (g_variant == 5) return launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream);        \
-  return half ? launch<AK, BKK, 64, 128, 1, 4>(d, ws, ws_bytes, stream)                      \
-              : launch<AK, BKK, 128, 128, 2, 2>(d, ws, ws_bytes, stream)
+  if (g_variant == 2)                                                                        \
+    return half ? launch<AK, BKK, 64, 128, 1, 4, 16, 1>(d, ws, ws_bytes, stream)             \
+                : launch<AK, BKK, 128, 128, 2, 2, 8, 1>(d, ws, ws_bytes, stream);            \
+  if (g_variant == 3)                                                                        \
+    return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 1>(d, ws, ws_bytes, stream)             \
+                : launch<AK, BKK, 128, 128, 2, 2, 32, 1>(d, ws, ws_bytes, stream);           \
+  return half ? launch<AK, BKK, 64, 128, 1, 4, 16, 1>(d, ws, ws_bytes, stream)               \
+              : launch<AK, BKK, 128, 128, 2, 2, 16, 1>(d, ws, ws_bytes, stream)
   if (!d.a_kmajor && !d.b_kmajor) { GEMM_PICK(0, 0); }
   if (!d.a_kmajor && d.b_kmajor) { GEMM_PICK(0, 1); }
   if (d.a_kmajor && d.b_kmajor) { GEMM_PICK(1, 1); }

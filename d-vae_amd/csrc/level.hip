@@ -17,8 +17,10 @@
 
 namespace {
 
-constexpr int BK = 32;
+constexpr int BK = 16;          // k-tile (measured best for these tiles, as in gemm.hip)
 constexpr int LDM = BK + 4;
+constexpr int KQ = BK / 4;      // float4 per tile row
+constexpr int RS = 256 / KQ;    // tile rows covered by one load step of the workgroup
 constexpr int BNG = 64;   // hidden units per workgroup
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -158,16 +160,19 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.f;
 
-  // one tile row = 8 float4; thread t covers row t/8 (+32 per step), quad t%8.  Rows beyond M
-  // are clamped to the last row (their results are never stored); K and HP are multiples of
-  // the tile sizes, so no load needs a predicate.
-  const int lr = tid >> 3, kq = (tid & 7) * 4;
+  // one tile row = KQ float4; thread t covers row t/KQ (+RS per step), quad t%KQ.  Rows beyond
+  // M are clamped to the last row (their results are never stored); K and HP are multiples
+  // of the tile sizes, so no load needs a predicate.
+  const int lr = tid / KQ, kq = (tid % KQ) * 4;
   const float* pa[NVA];
   const float* pb[NVB];
 #pragma unroll
-  for (int i = 0; i < NVA; ++i) pa[i] = p.A + (size_t)min(m0 + lr + 32 * i, p.M - 1) * p.lda + kq;
+  for (int i = 0; i < NVA; ++i) pa[i] = p.A + (size_t)min(m0 + lr + RS * i, p.M - 1) * p.lda + kq;
 #pragma unroll
-  for (int i = 0; i < NVB; ++i) pb[i] = p.W + ((size_t)(i >> 1) * p.HP + n0 + lr + 32 * (i & 1)) * p.ldw + kq;
+  for (int i = 0; i < NVB; ++i) {
+    const int row = lr + RS * i;   // LDS row = gate * 64 + hidden unit
+    pb[i] = p.W + ((size_t)(row / BNG) * p.HP + n0 + row % BNG) * p.ldw + kq;
+  }
   float4 va[NVA], vb[NVB];
   auto load = [&](int k0) {
 #pragma unroll
@@ -177,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
   };
   auto store = [&]() {
 #pragma unroll
-    for (int i = 0; i < NVA; ++i) st4(As + (lr + 32 * i) * LDM + kq, va[i]);
+    for (int i = 0; i < NVA; ++i) st4(As + (lr + RS * i) * LDM + kq, va[i]);
 #pragma unroll
-    for (int i = 0; i < NVB; ++i) st4(Bs + (lr + 32 * i) * LDM + kq, vb[i]);
+    for (int i = 0; i < NVB; ++i) st4(Bs + (lr + RS * i) * LDM + kq, vb[i]);
   };
   auto compute = [&]() {
 #pragma unroll
@@ -258,7 +263,7 @@ int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
 int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
                     const GruW& w, int HP, int prio, hipStream_t st) {
   if (p1 <= p0) return DVAE_OK;
-  DVAE_REQUIRE(HP % BNG == 0 && HP % BK == 0, "level_gru: HP must be a multiple of 64");
+  DVAE_REQUIRE(HP % BNG == 0, "level_gru: HP must be a multiple of 64");
   LevelCore c{};
   c.A = b.AGG + (size_t)p0 * HP; c.lda = HP; c.M = p1 - p0;
   c.W = w.Whh; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
@@ -269,7 +274,7 @@ int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const
 int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
                    int HP, int prio, hipStream_t st) {
   if (ne <= ns) return DVAE_OK;
-  DVAE_REQUIRE(HP % BNG == 0 && HP % BK == 0, "level_gm: HP must be a multiple of 64");
+  DVAE_REQUIRE(HP % BNG == 0, "level_gm: HP must be a multiple of 64");
   LevelCore c{};
   c.A = b.Hn + (size_t)ns * HP; c.lda = HP; c.M = ne - ns;
   c.W = Wgm; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
