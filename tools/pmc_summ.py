@@ -1,6 +1,6 @@
 """Summarise tools/pmc.sh output: per-kernel counter sums per train step."""
 import csv, glob, collections, sys
-tag = sys.argv[1]; steps = 3.0
+tag = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 def load(name):
     f = glob.glob('gpurun_out/pmc_%s_%s/*/*counter_collection.csv' % (tag, name))[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()
