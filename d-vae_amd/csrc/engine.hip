@@ -17,6 +17,7 @@
 
 namespace {
 
+
 struct LevelCfg {
   int fused_gm_min_rows; int fused_gru;
   LevelCfg() {
@@ -305,39 +306,9 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   return DVAE_OK;
 }
 
-// Weight-gradient products of the square matrices (W_hh, [Wg;Wm]) issued level by level
-// on the side stream while the reverse sweep is still running, so that only the last
-// level's products remain after the sweep (the first product writes, the rest accumulate
-// in level order: deterministic).
-struct LevelWgrad {
-  const G* gs; Events* ev; float* Ggru; float* Ggm;
-  bool wrote_gru = false, wrote_gm = false;
-  int gru_rows(hipStream_t st, const SweepBufs& b, int HP, int p0, int p1) {
-    if (p1 <= p0) return DVAE_OK;
-    DVAE_TRY(ev->edge(st, gs->st));
-    DVAE_TRY(gs->tn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, b.AGG + (size_t)p0 * HP, HP, Ggru, HP, 3 * HP, HP, p1 - p0,
-                    wrote_gru ? 1 : 0));
-    wrote_gru = true;
-    return DVAE_OK;
-  }
-  int gm_rows(hipStream_t st, const SweepBufs& b, int HP, int ns, int ne) {
-    if (ne <= ns) return DVAE_OK;
-    DVAE_TRY(ev->edge(st, gs->st));
-    DVAE_TRY(gs->tn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, b.Hn + (size_t)ns * HP, HP, Ggm, HP, 2 * HP, HP, ne - ns,
-                    wrote_gm ? 1 : 0));
-    wrote_gm = true;
-    return DVAE_OK;
-  }
-};
-
 // reverse-level sweep: DH holds dL/dHV on entry, dL/dAGG on exit
-// `pre(L)` (decoder): called before level L is processed; it must leave dL/dHV of the level's
-// prefix rows in DH and the level's extra final-state gradient in DHn.  pre(-1) covers the
-// k = 0 rows of levels >= 1, which are only needed after the loop.
-using PreLevel = std::function<int(int L)>;
-
 int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
-              bool seeded, const G& g, LevelWgrad* wg = nullptr, const PreLevel& pre = nullptr) {
+              bool seeded, const G& g) {
   const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
@@ -359,48 +330,35 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   float* dtarget = b.prefix ? b.DHn : b.DH;
   for (int L = lv.nlev - 1; L >= 0; --L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
-    if (pre) DVAE_TRY(pre(L));
     if (L + 1 < lv.nlev) {
       DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
-      if (wg) DVAE_TRY(wg->gm_rows(st, b, HP, ns, ne));
       DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
                     2 * HP, 1));
     }
     if (L == 0) {
       DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st));
-      if (seeded) {                                  // only node 0's h_in = h0 needs it
-        if (wg) DVAE_TRY(wg->gru_rows(st, b, HP, ns, ne));
-        DVAE_TRY(dagg_gemm(ns, ne));
-      }
+      if (seeded) DVAE_TRY(dagg_gemm(ns, ne));      // only node 0's h_in = h0 needs it
     } else {
       const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
       DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
-      if (wg) DVAE_TRY(wg->gru_rows(st, b, HP, p0, p1));
       DVAE_TRY(dagg_gemm(p0, p1));
     }
   }
   // k = 0 rows of the later levels feed nothing backwards except the weight gradients
-  if (b.prefix) {
-    if (pre) DVAE_TRY(pre(-1));
-    DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
-  }
+  if (b.prefix) DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
   return DVAE_OK;
 }
 
 // weight gradients of one sweep, reduced over all rows after the sweep.
 // Ggru -> dWhh [3HP][HP]; Xgru / Xgm -> the gradient-only regions of layout.h
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g,
-                const LevelWgrad* done = nullptr) {
+                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g) {
   const int HP = d.HP, PP = pos_cols(d), R = lv.R;
   hipStream_t st = g.st;
   const int RH = R > 0 ? b.RH : 0;
   const int z1 = (R > 0 && lv.nlev > 0) ? lv.ls[1] : 0;
   // dWhh = dgh^T . h_in over the rows whose h_in is not identically zero
-  if (done) {
-    // the sweep already issued these level by level; cover the "no rows at all" case
-    if (!done->wrote_gru) DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, 0));
-  } else if (!b.prefix) {
+  if (!b.prefix) {
     const int skip = d.mod == 0 ? z1 : 0;      // level 0 of a node sweep has h_in = 0
     DVAE_TRY(g.tn(b.GH + (size_t)skip * 3 * HP, 3 * HP, b.AGG + (size_t)skip * HP, HP, Ggru, HP, 3 * HP, HP,
                   R - skip));
@@ -414,8 +372,7 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
   DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xgru + (size_t)3 * HP * 32, 32, HP, 32, RH));
   if (d.mod == 0) {
     const int Rg = lv.nlev > 0 ? lv.ls[lv.nlev - 1] : 0;   // nodes that have a gate/map output
-    if (!done) DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
-    else if (!done->wrote_gm) DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, 0));
+    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
     DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
     DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, PP, Xgm, PP, 2 * HP, PP, Rg));
   } else {
@@ -498,7 +455,6 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
   const Scratch& ssc = w.sc[1];
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, ZP = d.ZP;
-  const bool per_level = d.mod == 0;   // see LevelWgrad (same summation order with or without a side stream)
 
   // heads
   DVAE_TRY(k_pad_rows(d_mu, B, d.Z, w.DML, 2 * ZP, ZP, st));
@@ -533,19 +489,17 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     DVAE_TRY(ev.edge(st, sd));
     DVAE_TRY(gs.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
     DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, ssc.part, ssc.part_floats, sd));
-    LevelWgrad wgr{&gs, &ev, Gp + L.gru_b, Gp + L.gm_b};
-    DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g, per_level ? &wgr : nullptr));
+    DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g));
     DVAE_TRY(ev.edge(st, sd));
     DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b,
-                         false, gs, per_level ? &wgr : nullptr));
+                         false, gs));
   } else {
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
-  LevelWgrad wgf{&gs, &ev, Gp + L.gru_f, Gp + L.gm_f};
-  DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g, per_level ? &wgf : nullptr));
+  DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, false,
-                       gs, per_level ? &wgf : nullptr));
+                       gs));
   return DVAE_OK;
 }
 
@@ -598,12 +552,16 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(ev.edge(sd, st));
   // add_vertex on the graph state seen before each node (dvae_model.py:199-200,251-257): MFMA
   // work on the side stream, beside the bandwidth-bound pair scorer on the chain
-  DVAE_TRY(ev.edge(st, sd));
-  DVAE_TRY(k_graph_state_fwd(S, R, d.N, d.mod, w.s.Hn, w.H0, w.GS, HP, sd));
-  DVAE_TRY(gs.nt(w.GS, HP, P + L.Wv1, HP, w.VH, d.VHP, R, d.VHP, HP, P + L.bv1, 1));
-  DVAE_TRY(gs.nt(w.VH, d.VHP, P + L.Wv2, d.VHP, w.TL, d.CP, R, d.CP, d.VHP, P + L.bv2));
-  DVAE_CHECK_HIP(hipMemsetAsync(type_logits, 0, (size_t)B * d.N * d.C * 4, sd));
-  DVAE_TRY(k_rows_to_dense(S, R, w.TL, d.CP, type_logits, d.N, d.C, sd));
+  // (DVAE_AV_MAIN=1 keeps it on the chain: A-B tests)
+  static const bool av_main = getenv("DVAE_AV_MAIN") != nullptr;
+  hipStream_t av = av_main ? st : sd;
+  const G& gav = av_main ? g : gs;
+  DVAE_TRY(ev.edge(st, av));
+  DVAE_TRY(k_graph_state_fwd(S, R, d.N, d.mod, w.s.Hn, w.H0, w.GS, HP, av));
+  DVAE_TRY(gav.nt(w.GS, HP, P + L.Wv1, HP, w.VH, d.VHP, R, d.VHP, HP, P + L.bv1, 1));
+  DVAE_TRY(gav.nt(w.VH, d.VHP, P + L.Wv2, d.VHP, w.TL, d.CP, R, d.CP, d.VHP, P + L.bv2));
+  DVAE_CHECK_HIP(hipMemsetAsync(type_logits, 0, (size_t)B * d.N * d.C * 4, av));
+  DVAE_TRY(k_rows_to_dense(S, R, w.TL, d.CP, type_logits, d.N, d.C, av));
   if (states) {
     DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
     DVAE_TRY(k_rows_to_dense(S, R, w.s.Hn, HP, states, d.N, d.H, st));
@@ -636,18 +594,24 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const int HP = d.HP, B = d.B, R = lv.R, RH = lv.R + lv.E, EHP = d.EHP;
 
   // ---- add_vertex backward (MFMA-bound) runs on the side stream beside the bandwidth-bound
-  // pair-scorer backward on the chain; then every weight-gradient product follows there ----
+  // pair-scorer backward on the chain; then every weight-gradient product follows there
+  // (DVAE_AV_MAIN=1 keeps the input-gradient part on the chain: A-B tests) ----
+  static const bool av_main = getenv("DVAE_AV_MAIN") != nullptr;
+  hipStream_t av = av_main ? st : sd;
+  const G& gav = av_main ? g : gs;
   DVAE_TRY(ev.edge(st, sd));
-  DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, sd));
-  DVAE_TRY(gs.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
-  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, sd));
+  DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, av));
+  DVAE_TRY(gav.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
+  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, av));
   // the graph state seen by add_vertex at node i is the state of node i-1 (bn: all earlier
   // nodes), which may sit in any level: this product cannot follow the sweep level by level
-  DVAE_TRY(gs.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
+  DVAE_TRY(gav.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
   hipEvent_t dgs_done = nullptr;
-  if (sd != st) {
+  if (av != st) {
     DVAE_TRY(ev.take(&dgs_done));
     DVAE_CHECK_HIP(hipEventRecord(dgs_done, sd));
+  } else {
+    DVAE_TRY(ev.edge(st, sd));
   }
   DVAE_TRY(gs.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
   DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, ssc.part, ssc.part_floats, sd));
@@ -667,37 +631,16 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_CHECK_HIP(hipMemsetAsync(w.DH0, 0, (size_t)B * HP * 4, st));
   DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
 
-  // ---- level sweep; the add_edge input gradients (dA.W1a -> dL/dHV of the prefix rows,
-  // dBq.W1b -> the final states) are produced level by level just ahead of it, so the
-  // sweep starts after the last level's slice instead of after the whole product ----
+  // ---- add_edge input gradients, then the level sweep ----
+  // (measured and dropped: producing dA.W1a / dBq.W1b level by level just ahead of the sweep and
+  // issuing the sweep's weight-gradient products level by level behind it -- the smaller launches
+  // cost more than the earlier start and the shorter tail gave: +0.5 ms at B=4096)
+  DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
+  DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, R, HP, EHP, 1));
   SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
-  const int z1 = (R > 0 && lv.nlev > 0) ? lv.ls[1] : R;
-  auto dh_rows = [&](int p0, int p1) {
-    return g.nn(w.DA + (size_t)p0 * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)p0 * HP, HP, p1 - p0, HP, EHP);
-  };
-  auto dhn_rows = [&](int ns, int ne) {
-    return g.nn(w.DBq + (size_t)ns * EHP, EHP, P + L.W1b, HP, w.s.DHn + (size_t)ns * HP, HP, ne - ns, HP, EHP, 1);
-  };
-  PreLevel pre = [&](int Lv) -> int {
-    if (Lv < 0) return dh_rows(z1, R);
-    DVAE_TRY(dhn_rows(lv.ls[Lv], lv.ls[Lv + 1]));
-    if (Lv == 0) return dh_rows(0, z1);
-    return dh_rows(R + lv.es[Lv], R + lv.es[Lv + 1]);
-  };
-  const bool per_level = d.mod == 0;   // see LevelWgrad (same summation order with or without a side stream)
-  LevelWgrad wgl{&gs, &ev, Gp + L.gru, Gp + L.gm};
-  if (R > 0) {
-    if (d.mod == 1 || lv.nlev <= 0) {   // one "level": whole products
-      DVAE_TRY(dh_rows(0, RH));
-      DVAE_TRY(dhn_rows(0, R));
-      DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, nullptr));
-    } else {
-      DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, per_level ? &wgl : nullptr, pre));
-    }
-  }
+  DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
   DVAE_TRY(ev.edge(st, sd));
-  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs,
-                       per_level ? &wgl : nullptr));
+  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
 

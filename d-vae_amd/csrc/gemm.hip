@@ -32,7 +32,7 @@ static int g_splitk_blocks = 768;   // tuning knob: workgroups a split-K launch 
 static int g_force_prio = -1;       // tuning knob: -1 as requested by the caller, 0/1 override
 static int g_dbg = 0;
 extern "C" int dvae_gemm_dbg(int v) { g_dbg = v; return 0; }
-static int g_variant = 0;           // lab knob: 0 default (BK16), 2 BK8 for 128x128, 3 BK32
+static int g_variant = 0;           // lab knob: 0 default (k-tile 16), 3 k-tile 32
 extern "C" int dvae_gemm_variant(int v) { g_variant = v; return 0; }
 
 namespace {
@@ -138,8 +138,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + j;
 }
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmParams p) {
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2>
+__global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
   using TA = Tile<AKM, BM, BK>;
@@ -356,7 +356,7 @@ void gemm_prof_end(void* h, hipStream_t st) { prof_end(static_cast<GemmProf*>(h)
 
 namespace {
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1, int MINB = 2>
 int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   GemmParams p;
   p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias;
@@ -395,7 +395,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     p.c_split = 0;
   }
   GemmProf* pr = prof_begin(AKM * 2 + BKM, 2.0 * d.M * d.N * d.K, stream);
-  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST>), dim3(p.nblk, splits), dim3(256), 0,
+  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST, MINB>), dim3(p.nblk, splits), dim3(256), 0,
                      stream, p);
   prof_end(pr, stream);
   DVAE_LAUNCH_CHECK();
@@ -452,9 +452,6 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
 #define GEMM_PICK(AK, BKK)                                                                   \
   if (narrow) return launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream);                \
   if (quarter) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);                \
-  if (g_variant == 2)                                                                        \
-    return half ? launch<AK, BKK, 64, 128, 1, 4, 16, 1>(d, ws, ws_bytes, stream)             \
-                : launch<AK, BKK, 128, 128, 2, 2, 8, 1>(d, ws, ws_bytes, stream);            \
   if (g_variant == 3)                                                                        \
     return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 1>(d, ws, ws_bytes, stream)             \
                 : launch<AK, BKK, 128, 128, 2, 2, 32, 1>(d, ws, ws_bytes, stream);           \

@@ -22,7 +22,7 @@ for lay, M, N, K in shapes:
         A = torch.randn(K, M, device=dev); B = torch.randn(K, N, device=dev); akm, bkm = 1, 1
     C = torch.empty(M, N, device=dev)
     line = '%s M=%6d N=%5d K=%6d ' % (lay, M, N, K)
-    for mode in (0, 3, 2):
+    for mode in (0, 3):
         lib.dvae_gemm_variant(mode)
         def run():
             E.check(lib.dvae_gemm_f32(E._ptr(A), A.stride(0), akm, E._ptr(B), B.stride(0), bkm, E._ptr(C), N, M, N, K,
