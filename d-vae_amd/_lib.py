@@ -55,11 +55,12 @@ SIGNATURES = {
     "dvae_gemm_tune": (c_int, [c_int, c_int]),
     "dvae_gemm_variant": (c_int, [c_int]),
     "dvae_gemm_dbg": (c_int, [c_int]),
-    "dvae_level_tune": (c_int, [c_int, c_int]),
+    "dvae_level_tune": (c_int, [c_int, c_int, c_int]),
     "dvae_gemm_profile": (c_int, [c_int]),
     "dvae_gemm_profile_read": (c_int, [c_void_p]),
     "dvae_sched_bytes": (c_size_t, [c_int, c_int]),
     "dvae_sched_build": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dvae_sched_types": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dvae_sched_export": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dvae_enc_param_floats": (c_size_t, [_P(DvaeDims)]),
     "dvae_dec_param_floats": (c_size_t, [_P(DvaeDims)]),

@@ -19,8 +19,9 @@ namespace {
 
 
 struct LevelCfg {
-  int fused_gm_min_rows; int fused_gru;
+  int fused_gm_min_rows; int fused_gru; int type_share;
   LevelCfg() {
+    type_share = getenv("DVAE_NO_TYPE_SHARE") ? 0 : 1;
     fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : 2048;
     fused_gru = (!getenv("DVAE_UNFUSED") && getenv("DVAE_FUSED_GRU")) ? 1 : 0;
   }
@@ -117,6 +118,7 @@ struct DecWs {
   float *ZPAD, *H0, *DH0, *DZP;
   float *A, *DA, *Bq, *DBq, *Cq, *DCq;
   float *GS, *DGS, *VH, *DVH, *TL, *DTL;
+  float *TYPEV, *AT, *DTT, *DTV, *REP;   // type-shared prefix rows (sched.h TypeShare)
   Scratch sc[2];
   size_t bytes;
 };
@@ -142,6 +144,11 @@ DecWs dec_ws(const dvae_dims& d, int R, int E, void* base) {
   w.DVH = c.f(r * d.VHP);
   w.TL = c.f(r * d.CP);
   w.DTL = c.f(r * d.CP);
+  w.TYPEV = c.f((size_t)32 * d.HP);
+  w.AT = c.f((size_t)32 * d.EHP);
+  w.DTT = c.f((size_t)d.EHP * 32);
+  w.DTV = c.f((size_t)32 * d.HP);
+  w.REP = c.f(64);
   carve_scratch(c, d, w.sc);
   w.bytes = c.off;
   return w;
@@ -230,6 +237,12 @@ int check_info(const dvae_dims& d, const int* info) {
   }
   DVAE_REQUIRE(info[1] >= 0 && info[1] <= d.B * d.N, "schedule info is stale or corrupt");
   return DVAE_OK;
+}
+
+// every node encoding is one-hot (dvae_sched_types) and there are levels >= 1: the decoder's
+// k = 0 prefix rows of those levels are shared by node type (sched.h TypeShare)
+bool type_shared(const dvae_dims& d, const int* info, const Levels& lv) {
+  return g_level_cfg.type_share && info[5] == 1 && d.mod == 0 && lv.nlev > 1 && lv.R > lv.ls[1];
 }
 
 struct SweepW {
@@ -538,9 +551,20 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
   // add_edge's first layer, split by input block (dvae_model.py:211-218), follows the
   // sweep level by level on the side stream
   SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
+  const bool typed = type_shared(d, info, lv);
+  const int z1 = lv.nlev > 0 ? lv.ls[1] : R;
+  TypeShare ts{nullptr, z1};
+  if (typed) {
+    // rows with (type, h_in = 0): one table row per type instead of one GEMM row per node
+    DVAE_TRY(ev.edge(st, sd));
+    DVAE_TRY(k_type_states(d.C, sw.gru, w.TYPEV, HP, sd));
+    DVAE_TRY(gs.nt(w.TYPEV, HP, P + L.W1a, HP, w.AT, EHP, 32, EHP, HP));
+    ts.AT = w.AT;
+  }
   LevelHook hook = [&](int p0, int p1, int ns, int ne) -> int {
     DVAE_TRY(ev.edge(st, sd));
-    DVAE_TRY(gs.nt(w.s.HV + (size_t)p0 * HP, HP, P + L.W1a, HP, w.A + (size_t)p0 * EHP, EHP, p1 - p0, EHP, HP));
+    if (!(typed && p0 >= z1 && p1 <= R))
+      DVAE_TRY(gs.nt(w.s.HV + (size_t)p0 * HP, HP, P + L.W1a, HP, w.A + (size_t)p0 * EHP, EHP, p1 - p0, EHP, HP));
     DVAE_TRY(gs.nt(w.s.Hn + (size_t)ns * HP, HP, P + L.W1b, HP, w.Bq + (size_t)ns * EHP, EHP, ne - ns, EHP, HP,
                    P + L.b1));
     return DVAE_OK;
@@ -566,7 +590,7 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
     DVAE_TRY(k_rows_to_dense(S, R, w.s.Hn, HP, states, d.N, d.H, st));
   }
-  DVAE_TRY(k_pair_fwd(sv, R, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
+  DVAE_TRY(k_pair_fwd(sv, ts, R, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
   DVAE_TRY(ev.edge(sd, st));
   return DVAE_OK;
 }
@@ -618,12 +642,35 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(gs.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
   DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, ssc.part, ssc.part_floats, sd));
 
-  DVAE_TRY(k_pair_bwd_a(sv, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part, msc.part_floats,
-                        EHP, st));
-  DVAE_TRY(k_pair_bwd_b(sv, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
+  SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
+  const bool typed = type_shared(d, info, lv);
+  const int z1 = lv.nlev > 0 ? lv.ls[1] : R;
+  const TypeShare ts{typed ? w.AT : nullptr, z1};
+  DVAE_TRY(k_pair_bwd_a(sv, ts, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part,
+                        msc.part_floats, EHP, st));
+  DVAE_TRY(k_pair_bwd_b(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
   DVAE_TRY(ev.edge(st, sd));
-  DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
+  hipEvent_t k0_done = nullptr;
+  if (typed) {
+    // type-shared rows [z1,R): their gradients meet in the per-type sums DTT = DA^T . onehot(type)
+    //   d hv(type) = DTT^T . W1a  -> handed to the type's first row for the GRU backward (the
+    //                               other rows of the type get zero: same linear map for all)
+    //   dW1a      += DTT . hv(type)
+    DVAE_TRY(k_build_xp(S, 1, RH, x, d.N, d.C, w.s.XP, sd));
+    DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
+    DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
+    DVAE_TRY(k_type_scatter(sv.row_type, z1, R, w.DTV, reinterpret_cast<int*>(w.REP), w.s.DH, HP, sd));
+    if (sd != st) {
+      DVAE_TRY(ev.take(&k0_done));
+      DVAE_CHECK_HIP(hipEventRecord(k0_done, sd));
+    }
+    DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1));
+    DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R, 1));
+    DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
+  } else {
+    DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
+  }
   DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, R));
   DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
@@ -635,9 +682,14 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   // (measured and dropped: producing dA.W1a / dBq.W1b level by level just ahead of the sweep and
   // issuing the sweep's weight-gradient products level by level behind it -- the smaller launches
   // cost more than the earlier start and the shorter tail gave: +0.5 ms at B=4096)
-  DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
+  if (typed) {
+    DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, z1, HP, EHP));
+    DVAE_TRY(g.nn(w.DA + (size_t)R * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)R * HP, HP, RH - R, HP, EHP));
+    if (k0_done) DVAE_CHECK_HIP(hipStreamWaitEvent(st, k0_done, 0));
+  } else {
+    DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
+  }
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, R, HP, EHP, 1));
-  SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
   DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs));
@@ -676,9 +728,10 @@ extern "C" int dvae_side_stream_destroy(void* stream) {
 }
 
 // tuning / test knob: rows from which the gate/map step runs fused (-1 never, 0 always),
-// and whether the GRU step runs fused
-extern "C" int dvae_level_tune(int fused_gm_min_rows, int fused_gru) {
+// whether the GRU step runs fused, whether the decoder shares its type-only prefix rows
+extern "C" int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share) {
   g_level_cfg.fused_gm_min_rows = fused_gm_min_rows;
   g_level_cfg.fused_gru = fused_gru;
+  g_level_cfg.type_share = type_share;
   return DVAE_OK;
 }

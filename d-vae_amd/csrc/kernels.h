@@ -78,18 +78,24 @@ int k_chain_mask(const int* sizes, int B, int t, float* d_next, float* d_t, int 
 int k_chain_scatter(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* DCAT,
                     float* d_t, float* DHb, int HP, hipStream_t st);
 
+// type-shared prefix rows (sched.h TypeShare): TYPEV [32][HP] = GRU(one-hot c, h_in = 0);
+// DH[first row of type c in [r0,r1)] = T[c], DH[other rows] = 0  (rep: 32 ints of scratch)
+int k_type_states(int C, const GruW& w, float* TYPEV, int HP, hipStream_t st);
+int k_type_scatter(const int* row_type, int r0, int r1, const float* T, int* rep, float* DH, int HP,
+                   hipStream_t st);
+
 // decoder glue -----------------------------------------------------------------
 int k_graph_state_fwd(const SchedDir& S, int R, int N, int mod, const float* Hn, const float* h0, float* GS,
                       int HP, hipStream_t st);
 int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int* sizes, const float* DGS,
                       float* DHn, float* dh0, int HP, hipStream_t st);
-int k_pair_fwd(const SchedView& sv, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
+int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
                const float* b2, float* edge_logits, int EHP, hipStream_t st);
 // DA [RH][EHP]; out = dw2 [EHP] | db2 [4]
-int k_pair_bwd_a(const SchedView& sv, int R, int RH, const float* A, const float* Bq, const float* Cq,
+int k_pair_bwd_a(const SchedView& sv, const TypeShare& ts, int R, int RH, const float* A, const float* Bq, const float* Cq,
                  const float* w2, const float* d_edge, float* DA, float* out, float* part,
                  size_t part_floats, int EHP, hipStream_t st);
-int k_pair_bwd_b(const SchedView& sv, int R, const int* sizes, const float* A, const float* Bq,
+int k_pair_bwd_b(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,
                  const float* Cq, const float* w2, const float* d_edge, float* DBq, int EHP, hipStream_t st);
 // out[b] = sum over the graph's nodes of T[row]   (W % 4 == 0)
 int k_graph_sum(const SchedDir& S, const int* sizes, int B, int N, const float* T, int W, float* out,

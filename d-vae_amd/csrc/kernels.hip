@@ -112,6 +112,52 @@ __global__ void gru_fwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, in
   }
 }
 
+// GRU state of a node of type c whose h_in is 0: TYPEV[c] for c < C, zero rows up to 32.
+// Same arithmetic as gru_fwd_kernel's no_gh path on a one-hot encoding.
+__global__ void type_states_kernel(int C, GruW w, float* __restrict__ TYPEV, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)32 * HP4;
+  ITEM_LOOP(total) {
+    const int c = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    float4 hh = zero4();
+    if (c < C) {
+      float4 gi[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gi[g] = fma4(1.f, ld4(w.WihT + (size_t)c * 3 * HP + g * HP + j), ld4(w.bih + g * HP + j));
+      const float4 ghr = ld4(w.bhh + j), ghz = ld4(w.bhh + HP + j), ghn = ld4(w.bhh + 2 * HP + j);
+#define TS_LANE(f)                                                  \
+      {                                                             \
+        const float rr = sigm(gi[0].f + ghr.f), zz = sigm(gi[1].f + ghz.f); \
+        const float nn = tanhf(gi[2].f + rr * ghn.f);               \
+        hh.f = (1.f - zz) * nn + zz * 0.f;                          \
+      }
+      TS_LANE(x) TS_LANE(y) TS_LANE(z) TS_LANE(w)
+#undef TS_LANE
+    }
+    st4(TYPEV + (size_t)c * HP + j, hh);
+  }
+}
+
+// rep[c] = first node row in [r0, r1) of type c (rep preset to INT_MAX)
+__global__ void type_rep_kernel(const int* __restrict__ row_type, int r0, int r1, int* __restrict__ rep) {
+  for (int r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < r1; r += gridDim.x * blockDim.x)
+    atomicMin(rep + row_type[r], r);
+}
+
+// The rows of one type share ONE state, so the gradient of that state is the per-type SUM T[c];
+// every per-row operation downstream is the same linear map for all rows of a type, hence the
+// sum is handed to the type's first row and the other rows get zero.
+__global__ void type_scatter_kernel(const int* __restrict__ row_type, const int* __restrict__ rep, int r0, int r1,
+                                    const float* __restrict__ T, float* __restrict__ DH, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(r1 - r0) * HP4;
+  ITEM_LOOP(total) {
+    const int r = r0 + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int c = row_type[r];
+    st4(DH + (size_t)r * HP + j, rep[c] == r ? ld4(T + (size_t)c * HP + j) : zero4());
+  }
+}
+
 // gate/map epilogue, mod None: GMP holds h.[Wg;Wm][:, :H]^T; the position one-hot
 // columns and the biases come in as posb[i] (dvae_model.py:71-79)
 __global__ void gm_fwd_kernel(SchedDir S, int ns, int ne, float* __restrict__ GMP,
@@ -517,7 +563,7 @@ __global__ void add_rows_kernel(float* __restrict__ dst, int ldd, const float* _
 //   k = number of predecessors of i with index above j.  One wave per row.
 // ---------------------------------------------------------------------------
 template <int VPL>
-__global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, int R, const float* __restrict__ A,
+__global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, TypeShare ts, int R, const float* __restrict__ A,
                                                        const float* __restrict__ Bq,
                                                        const float* __restrict__ Cq,
                                                        const float* __restrict__ w2,
@@ -549,9 +595,10 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, int R, cons
         next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
       }
       if (t != cur) {
+        const float* ar = a_row(sv, ts, A, EHP, R, r, t);
 #pragma unroll
         for (int v = 0; v < VPL; ++v)
-          a[v] = add4(ld4(A + (size_t)prow_of(S, R, r, t) * EHP + (lane + 64 * v) * 4), c[v]);
+          a[v] = add4(ld4(ar + (lane + 64 * v) * 4), c[v]);
         cur = t;
       }
       const size_t rj = S.node2row[b * N + j];
@@ -572,7 +619,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, int R, cons
 
 // one wave per prefix row p = (i,k): pairs j in [u_{k+1}, u_k - 1]
 template <int VPL>
-__global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, int R, int RH, const float* __restrict__ A,
+__global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, TypeShare ts, int R, int RH, const float* __restrict__ A,
                                                          const float* __restrict__ Bq,
                                                          const float* __restrict__ Cq,
                                                          const float* __restrict__ w2,
@@ -599,10 +646,11 @@ __global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, int R, in
     const int hi = (k == 0 ? i : S.row_node[S.csr_idx[e0 + k - 1]]) - 1;
     const int lo = k < deg ? S.row_node[S.csr_idx[e0 + k]] : 0;
     float4 a[VPL], da[VPL];
+    const float* ar = p < R ? a_row(sv, ts, A, EHP, R, p, 0) : A + (size_t)p * EHP;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       da[v] = zero4();
-      a[v] = ld4(A + (size_t)p * EHP + (lane + 64 * v) * 4);
+      a[v] = ld4(ar + (lane + 64 * v) * 4);
       if (Cq) a[v] = add4(a[v], ld4(Cq + (size_t)b * EHP + (lane + 64 * v) * 4));
     }
     for (int j = lo; j <= hi; ++j) {
@@ -632,7 +680,7 @@ __global__ __launch_bounds__(256) void pair_bwd_a_kernel(SchedView sv, int R, in
 
 // one wave per node j: pairs (i,j) for every later node i of the same graph
 template <int VPL>
-__global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, int R, const int* __restrict__ sizes,
+__global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, TypeShare ts, int R, const int* __restrict__ sizes,
                                                          const float* __restrict__ A,
                                                          const float* __restrict__ Bq,
                                                          const float* __restrict__ Cq,
@@ -669,11 +717,11 @@ __global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, int R, co
         else if (w == (j >> 5)) m &= ((j & 31) == 31) ? 0u : (~0u << ((j & 31) + 1));
         k += __popc(m);
       }
-      const size_t pr = (size_t)prow_of(S, R, ri, k);
+      const float* ar = a_row(sv, ts, A, EHP, R, ri, k);
       const float ds = d_edge[((size_t)b * N + i) * N + j];
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
-        const float4 q = add4(bq[v], ld4(A + pr * EHP + (lane + 64 * v) * 4));
+        const float4 q = add4(bq[v], ld4(ar + (lane + 64 * v) * 4));
         if (q.x > 0.f) dbq[v].x = fmaf(ds, wv[v].x, dbq[v].x);
         if (q.y > 0.f) dbq[v].y = fmaf(ds, wv[v].y, dbq[v].y);
         if (q.z > 0.f) dbq[v].z = fmaf(ds, wv[v].z, dbq[v].z);
@@ -717,6 +765,23 @@ int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, 
   if (p1 <= p0) return DVAE_OK;
   hipLaunchKernelGGL(gru_fwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, b.R, p0, p1,
                      b.prefix, no_gh, b.GH, b.AGG, b.GHN, b.HV, b.Hn, x, N, C, w, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_type_states(int C, const GruW& w, float* TYPEV, int HP, hipStream_t st) {
+  hipLaunchKernelGGL(type_states_kernel, grid_for((long long)32 * (HP / 4)), dim3(256), 0, st, C, w, TYPEV, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_type_scatter(const int* row_type, int r0, int r1, const float* T, int* rep, float* DH, int HP,
+                   hipStream_t st) {
+  if (r1 <= r0) return DVAE_OK;
+  DVAE_CHECK_HIP(hipMemsetAsync(rep, 0x7f, 32 * sizeof(int), st));
+  hipLaunchKernelGGL(type_rep_kernel, grid_for(r1 - r0, 512), dim3(256), 0, st, row_type, r0, r1, rep);
+  hipLaunchKernelGGL(type_scatter_kernel, grid_for((long long)(r1 - r0) * (HP / 4)), dim3(256), 0, st, row_type,
+                     rep, r0, r1, T, DH, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
@@ -859,17 +924,17 @@ int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int
   return DVAE_OK;
 }
 
-int k_pair_fwd(const SchedView& sv, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
+int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
                const float* b2, float* edge_logits, int EHP, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
   const int grid = std::min(cdiv(R, 4), 4096);
-  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, sv, R, A, Bq, Cq, w2,
+  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, A, Bq, Cq, w2,
                                        b2, edge_logits));
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
 
-int k_pair_bwd_a(const SchedView& sv, int R, int RH, const float* A, const float* Bq, const float* Cq,
+int k_pair_bwd_a(const SchedView& sv, const TypeShare& ts, int R, int RH, const float* A, const float* Bq, const float* Cq,
                  const float* w2, const float* d_edge, float* DA, float* out, float* part,
                  size_t part_floats, int EHP, hipStream_t st) {
   if (RH <= 0) return DVAE_OK;
@@ -877,7 +942,7 @@ int k_pair_bwd_a(const SchedView& sv, int R, int RH, const float* A, const float
   int grid = std::min(cdiv(RH, 4), 512);
   grid = (int)std::min<size_t>(grid, part_floats / (per * 4));
   DVAE_REQUIRE(grid >= 1, "pair_bwd_a: scratch too small");
-  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_a_kernel<V>), dim3(grid), dim3(256), 0, st, sv, R, RH, A, Bq, Cq,
+  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_a_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, RH, A, Bq, Cq,
                                        w2, d_edge, DA, part));
   DVAE_LAUNCH_CHECK();
   // the scratch behind the per-wave partials holds the group sums of the two-stage reduction
@@ -885,11 +950,11 @@ int k_pair_bwd_a(const SchedView& sv, int R, int RH, const float* A, const float
   return reduce_parts_2stage(part, grid * 4, per, part + used, part_floats - used, out, per, st);
 }
 
-int k_pair_bwd_b(const SchedView& sv, int R, const int* sizes, const float* A, const float* Bq,
+int k_pair_bwd_b(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,
                  const float* Cq, const float* w2, const float* d_edge, float* DBq, int EHP, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
   const int grid = std::min(cdiv(R, 4), 4096);
-  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_b_kernel<V>), dim3(grid), dim3(256), 0, st, sv, R, sizes, A, Bq,
+  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_bwd_b_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, sizes, A, Bq,
                                        Cq, w2, d_edge, DBq));
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;

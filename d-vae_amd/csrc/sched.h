@@ -28,6 +28,8 @@ struct SchedView {
   int* err;           // [1]
   int* scan_tmp;      // tile sums for the scan
   int* info;          // [DVAE_SCHED_INFO_INTS(N)] device copy of info_host
+  int* row_type;      // [RM] forward node row -> node type if its encoding is exactly one-hot,
+                      //      else -1 (filled by dvae_sched_types; info[5] = 1 when every row has one)
   SchedDir dir[2];    // 0 forward, 1 reverse
 };
 
@@ -43,3 +45,17 @@ __host__ __device__ static inline int final_prow(const SchedDir& S, int R, int r
   return e1 == S.csr_ptr[r] ? r : R + e1 - 1;
 }
 SchedView sched_view(void* base, int B, int N);
+
+// Decoder k = 0 prefix rows of levels >= 1 have h_in = 0, so their GRU state -- and with it
+// their add_edge first-layer row A = W1a.hv -- depends on the node TYPE only.  When every
+// node encoding of the batch is exactly one-hot (info[5]), those rows are served from a
+// C-row table instead of being computed per row.  AT == NULL: off.
+struct TypeShare {
+  const float* AT;   // [32][EHP] W1a . hv(type)
+  int z1;            // node rows >= z1 (levels >= 1) share by type
+};
+__host__ __device__ static inline const float* a_row(const SchedView& sv, const TypeShare& ts, const float* A,
+                                                     int EHP, int R, int r, int k) {
+  if (k == 0 && ts.AT && r >= ts.z1) return ts.AT + (size_t)sv.row_type[r] * EHP;
+  return A + (size_t)prow_of(sv.dir[0], R, r, k) * EHP;
+}

@@ -5,6 +5,8 @@
 // 128-bit masks.
 #include "sched.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int SCAN_TILE = 2048;  // ints per 256-thread block
@@ -32,6 +34,7 @@ SchedView carve(void* base, int B, int N, size_t* total) {
   v.err = c.take<int>(64);
   v.scan_tmp = c.take<int>((size_t)cdiv(v.RM + N + 2, SCAN_TILE) + 64);
   v.info = c.take<int>(DVAE_SCHED_INFO_INTS(N));
+  v.row_type = c.take<int>(v.RM);
   for (int d = 0; d < 2; ++d) {
     SchedDir& s = v.dir[d];
     s.level = c.take<int>(v.RM);
@@ -333,9 +336,43 @@ __global__ void sched_info_kernel(SchedView s, int want_rev) {
   info[5] = info[6] = info[7] = 0;
 }
 
+// node type of every forward node row; err[1] counts rows whose encoding is not one-hot
+__global__ void sched_types_kernel(SchedView s, const float* __restrict__ x, int C) {
+  const int R = s.dir[0].pos[(size_t)s.N * s.B];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
+    const float* xr = x + ((size_t)s.dir[0].row_graph[r] * s.N + s.dir[0].row_node[r]) * C;
+    int t = -1, ones = 0, other = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = xr[c];
+      if (v == 1.f) { t = c; ++ones; }
+      else if (v != 0.f) ++other;
+    }
+    if (ones != 1 || other != 0) { t = -1; atomicAdd(s.err + 1, 1); }
+    s.row_type[r] = t;
+  }
+}
+
+__global__ void sched_types_info_kernel(SchedView s) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) s.info[5] = s.err[1] == 0 ? 1 : 0;
+}
+
 }  // namespace
 
 SchedView sched_view(void* base, int B, int N) { return carve(base, B, N, nullptr); }
+
+extern "C" int dvae_sched_types(const float* x, int B, int N, int C, void* sched, int* info_host, void* stream) {
+  DVAE_REQUIRE(x && sched && info_host, "sched_types: null pointer");
+  DVAE_REQUIRE(B > 0 && N > 0 && N <= DVAE_MAX_N && C > 0 && C < DVAE_MAX_C, "sched_types: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  SchedView s = sched_view(sched, B, N);
+  DVAE_CHECK_HIP(hipMemsetAsync(s.err + 1, 0, sizeof(int), st));
+  const int grid = std::min(cdiv(B * N, 256), 2048);
+  hipLaunchKernelGGL(sched_types_kernel, dim3(grid), dim3(256), 0, st, s, x, C);
+  hipLaunchKernelGGL(sched_types_info_kernel, dim3(1), dim3(64), 0, st, s);
+  DVAE_LAUNCH_CHECK();
+  DVAE_CHECK_HIP(hipMemcpyAsync(info_host + 5, s.info + 5, sizeof(int), hipMemcpyDeviceToHost, st));
+  return DVAE_OK;
+}
 
 extern "C" size_t dvae_sched_bytes(int B, int N) {
   size_t total = 0;

@@ -82,7 +82,7 @@ class Schedule:
     wait happens on first use -- built one batch ahead, it costs nothing.
     """
 
-    def __init__(self, g, sizes=None, want_reverse=False, stream=None, defer=False):
+    def __init__(self, g, sizes=None, want_reverse=False, stream=None, defer=False, x=None):
         _require_cuda(g, "X['graph']")
         assert g.dim() == 3 and g.shape[1] == g.shape[2], "graph must be [B,N,N]"
         lib = load()
@@ -98,6 +98,13 @@ class Schedule:
             check(lib.dvae_sched_build(_ptr(self.g), _ptr(self.sizes), self.B, self.N, int(self.want_reverse),
                                        _ptr(self.buf), ctypes.c_void_p(self._pin.data_ptr()),
                                        ctypes.c_void_p(self.stream.cuda_stream)))
+            if x is not None:
+                # node types: lets the decoder share its type-only prefix rows (dvae_sched_types)
+                assert x.dim() == 3 and x.shape[0] == self.B and x.shape[1] == self.N, "node_encoding must be [B,N,C]"
+                self._x = _f32c(x)
+                check(lib.dvae_sched_types(_ptr(self._x), self.B, self.N, int(x.shape[2]), _ptr(self.buf),
+                                           ctypes.c_void_p(self._pin.data_ptr()),
+                                           ctypes.c_void_p(self.stream.cuda_stream)))
             self.event = torch.cuda.Event()
             self.event.record(self.stream)
         self._info = None
@@ -141,6 +148,11 @@ class Schedule:
     @property
     def nlev_rev(self):
         return int(self.info[4])
+
+    @property
+    def onehot(self):
+        """True when dvae_sched_types ran and found every node encoding one-hot."""
+        return int(self.info[5]) == 1
 
     @property
     def info_ptr(self):

@@ -221,8 +221,8 @@ class Dvae(nn.Module):
         return E.ReparamFn.apply(mu, logvar, eps)
 
     def _schedule(self, X):
-        g, _, sizes = _batch_parts(X)
-        return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional)
+        g, x, sizes = _batch_parts(X)
+        return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, x=x)
 
     def forward(self, X, eps=None):
         sched = self._schedule(X)
@@ -311,13 +311,13 @@ class Dvae(nn.Module):
         return at once; pass the result to ``loss_and_grad(batch, sched=...)``.  A data
         loader that calls this one batch ahead hides the schedule's host round trip
         (its build kernels run beside the previous step when ``resident``)."""
-        g, _, sizes = _batch_parts(batch)
+        g, x, sizes = _batch_parts(batch)
         dev = g.device
         if self._prep is None or self._prep.device != dev:
             self._prep = torch.cuda.Stream(device=dev)
         if not resident:   # resident=True: the batch tensors are complete already, start at once
             self._prep.wait_stream(torch.cuda.current_stream())
-        return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, stream=self._prep, defer=True)
+        return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, stream=self._prep, defer=True, x=x)
 
     def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, sched=None):
         """Forward + backward of training_step's loss without building an autograd

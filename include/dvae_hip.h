@@ -95,6 +95,7 @@ int dvae_gemm_profile_read(double* out12_host);
  *        stream has been synchronised:
  *          [0] error flag (0 ok)   [1] R = valid nodes   [2] E = edges
  *          [3] forward level count [4] reverse level count
+ *          [5] 1 after dvae_sched_types found every node encoding one-hot, else 0
  *          [8 .. 8+N]        forward level starts (node rows), [8+nlev] = R
  *          [8+N+1 .. 8+2N+1] reverse level starts
  *          [8+2N+2 .. 8+3N+2] forward level starts in edge space (csr_ptr there)
@@ -103,6 +104,13 @@ int dvae_gemm_profile_read(double* out12_host);
 size_t dvae_sched_bytes(int B, int N);
 int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_reverse, void* sched,
                      int* info_host, void* stream);
+/* Optional second step of the schedule (same stream, before waiting for info_host): looks at
+ * the node encodings x [B][N][C] (dataloader.py:62-73 builds them one-hot) and sets
+ * info_host[5] = 1 when every valid node's row is exactly one-hot.  The decoder then serves
+ * the prefix rows whose GRU input is (type, h_in = 0) from a C-row table instead of
+ * computing them per row (about a third of add_edge's first-layer work at ENAS sizes);
+ * without this call, or with other encodings, every row is computed. */
+int dvae_sched_types(const float* x, int B, int N, int C, void* sched, int* info_host, void* stream);
 /* copies one int32 array of the schedule to `out` (device); which:
  * 0 level_fwd[B*N] 1 level_rev[B*N] 2 node2row_fwd[B*N] 3 node2row_rev[B*N]
  * 4 csr_ptr_fwd[R+1] 5 csr_idx_fwd[E] 6 row_graph_fwd[R] 7 row_node_fwd[R] */
@@ -193,8 +201,10 @@ int dvae_decoder_bwd(const dvae_dims* d, const float* z, const float* x, const i
 /* Tuning / test knob of the forward level sweep (no counterpart in the reference): node rows
  * per level from which the gate/map step runs as ONE fused launch (GEMM + sigmoid*map
  * epilogue; -1 never, 0 always, default 2048) and whether the GRU step runs fused (hidden
- * GEMM + gates in one launch; default 0).  Every combination computes the same formulas (fp32 summation order may differ). */
-int dvae_level_tune(int fused_gm_min_rows, int fused_gru);
+ * GEMM + gates in one launch; default 0); type_share: whether the decoder serves its type-only
+ * prefix rows from the per-type table when dvae_sched_types allows it (default 1).  Every
+ * combination computes the same formulas (fp32 summation order may differ). */
+int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share);
 
 /* Side stream for the *_fwd / *_bwd calls above (no counterpart in the reference).
  * It is created with the LOWEST scheduling priority the device offers, so that the

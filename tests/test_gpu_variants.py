@@ -36,12 +36,12 @@ def test_fused_level_kernels(cuda, bidir):
     lib = _lib.load()
     model, X, eps = _setup(cuda, 96, bidir=bidir, H=501 if not bidir else 128)
     try:
-        lib.dvae_level_tune(-1, 0)
+        lib.dvae_level_tune(-1, 0, 1)
         ref = _step(model, X, eps)
         with torch.no_grad():
             ref_states = model.encoder.node_states(X)[0].clone()
         for gm_min, gru in ((0, 0), (0, 1), (-1, 1)):
-            lib.dvae_level_tune(gm_min, gru)
+            lib.dvae_level_tune(gm_min, gru, 1)
             out = _step(model, X, eps)
             with torch.no_grad():
                 states = model.encoder.node_states(X)[0]
@@ -52,7 +52,7 @@ def test_fused_level_kernels(cuda, bidir):
             rel = float((out[1] - ref[1]).norm() / ref[1].norm())
             assert rel <= 1e-3, "gradients %d/%d: relative L2 error %.3e" % (gm_min, gru, rel)
     finally:
-        lib.dvae_level_tune(2048, 0)
+        lib.dvae_level_tune(2048, 0, 1)
 
 
 def test_prepared_schedule_bitwise(cuda):
@@ -74,3 +74,43 @@ def test_prepared_schedule_rejects_bad_graph(cuda):
     sched = model.prepare(bad)
     with pytest.raises(_lib.GraphError):
         model.loss_and_grad(bad, eps=eps, sched=sched)
+
+
+def test_type_shared_rows_match_per_row(cuda):
+    """One-hot node encodings: the decoder's (type, h_in = 0) prefix rows come from a C-row table
+    (dvae_sched_types / TypeShare) -- same results as computing every row."""
+    from dvae_amd import _lib
+    lib = _lib.load()
+    model, X, eps = _setup(cuda, 300)
+    assert model._schedule(X).onehot
+    try:
+        lib.dvae_level_tune(2048, 0, 0)
+        ref = _step(model, X, eps)
+        lib.dvae_level_tune(2048, 0, 1)
+        out = _step(model, X, eps)
+    finally:
+        lib.dvae_level_tune(2048, 0, 1)
+    close_scaled(out[0], ref[0], tol=1e-5, what="losses")
+    rel = float((out[1] - ref[1]).norm() / ref[1].norm())      # ReLU kinks: see test_fused_level_kernels
+    assert rel <= 1e-3, "gradients: relative L2 error %.3e" % rel
+
+
+def test_soft_node_encodings_fall_back_to_per_row(cuda):
+    """Encodings that are not one-hot (the API takes any float rows): the schedule says so and
+    every row is computed; checked against the oracle."""
+    from oracle import dense_ref as O
+    from helpers import oracle_sd
+    model, X, eps = _setup(cuda, 6, H=64)
+    gen = torch.Generator().manual_seed(8)
+    xs = torch.rand(X['node_encoding'].shape, generator=gen)
+    Xs = {'graph': X['graph'], 'node_encoding': xs.to(cuda)}
+    assert not model._schedule(Xs).onehot
+    sd = oracle_sd(model, requires_grad=True)
+    ref = O.train_loss(sd, X['graph'].cpu(), xs, eps.cpu(), None, False)
+    ref[0].backward()
+    out = _step(model, Xs, eps)
+    assert abs(float(out[0][3]) - float(ref[0])) <= 1e-4 * abs(float(ref[0]))
+    params = dict(model.named_parameters())
+    for k, r in sd.items():
+        if k in params and r.grad is not None:
+            close_scaled(params[k].grad, r.grad, tol=3e-4, what="grad " + k)
