@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvae_hip.so")
+# DVAE_LIB: another build of the same library (same-box A-B timing of kernel changes)
+LIB_PATH = os.environ.get("DVAE_LIB") or os.path.join(_HERE, "libdvae_hip.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

@@ -257,7 +257,8 @@ using LevelHook = std::function<int(int p0, int p1, int ns, int ne)>;
 // the k = 0 states (h_in = 0, or h0 for node 0 -> only level 0 needs the hidden GEMM);
 // edge rows R + [es[L], es[L+1]) carry the running predecessor sums.
 int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
-              const float* x, const float* h0, const G& g, const LevelHook& hook = nullptr) {
+              const float* x, const float* h0, const G& g, const LevelHook& hook = nullptr,
+              bool k0_shared = false) {
   const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
@@ -290,7 +291,8 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     return DVAE_OK;
   }
   // rows whose h_in is 0 depend on nothing but the node type: all levels in one launch
-  if (b.prefix) {
+  // (k0_shared: those rows are served per type, sched.h TypeShare -- nothing to compute per row)
+  if (b.prefix && !k0_shared) {
     DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
     if (hook) DVAE_TRY(hook(z1, R, 0, 0));
   }
@@ -321,7 +323,7 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
 
 // reverse-level sweep: DH holds dL/dHV on entry, dL/dAGG on exit
 int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
-              bool seeded, const G& g) {
+              bool seeded, const G& g, bool k0_shared = false) {
   const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
@@ -358,7 +360,7 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     }
   }
   // k = 0 rows of the later levels feed nothing backwards except the weight gradients
-  if (b.prefix) DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
+  if (b.prefix && !k0_shared) DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
   return DVAE_OK;
 }
 
@@ -563,13 +565,12 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
   }
   LevelHook hook = [&](int p0, int p1, int ns, int ne) -> int {
     DVAE_TRY(ev.edge(st, sd));
-    if (!(typed && p0 >= z1 && p1 <= R))
-      DVAE_TRY(gs.nt(w.s.HV + (size_t)p0 * HP, HP, P + L.W1a, HP, w.A + (size_t)p0 * EHP, EHP, p1 - p0, EHP, HP));
+    DVAE_TRY(gs.nt(w.s.HV + (size_t)p0 * HP, HP, P + L.W1a, HP, w.A + (size_t)p0 * EHP, EHP, p1 - p0, EHP, HP));
     DVAE_TRY(gs.nt(w.s.Hn + (size_t)ns * HP, HP, P + L.W1b, HP, w.Bq + (size_t)ns * EHP, EHP, ne - ns, EHP, HP,
                    P + L.b1));
     return DVAE_OK;
   };
-  DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g, hook));
+  DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g, hook, typed));
 
   // pair scores need every A / Bq row: the chain waits for the side stream's products here
   DVAE_CHECK_HIP(hipMemsetAsync(edge_logits, 0, (size_t)B * d.N * d.N * 4, st));
@@ -651,20 +652,15 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(k_pair_bwd_b(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
   DVAE_TRY(ev.edge(st, sd));
-  hipEvent_t k0_done = nullptr;
   if (typed) {
     // type-shared rows [z1,R): their gradients meet in the per-type sums DTT = DA^T . onehot(type)
-    //   d hv(type) = DTT^T . W1a  -> handed to the type's first row for the GRU backward (the
-    //                               other rows of the type get zero: same linear map for all)
+    //   d hv(type) = DTT^T . W1a  -> GRU backward once per type (k_type_gru_bwd)
     //   dW1a      += DTT . hv(type)
     DVAE_TRY(k_build_xp(S, 1, RH, x, d.N, d.C, w.s.XP, sd));
     DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
     DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
-    DVAE_TRY(k_type_scatter(sv.row_type, z1, R, w.DTV, reinterpret_cast<int*>(w.REP), w.s.DH, HP, sd));
-    if (sd != st) {
-      DVAE_TRY(ev.take(&k0_done));
-      DVAE_CHECK_HIP(hipEventRecord(k0_done, sd));
-    }
+    DVAE_TRY(k_type_gru_bwd(sv.row_type, z1, R, d.C, sw.gru, w.DTV, reinterpret_cast<int*>(w.REP), w.s.GH, w.s.GHN,
+                            HP, sd));
     DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1));
     DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R, 1));
     DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
@@ -685,12 +681,11 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   if (typed) {
     DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, z1, HP, EHP));
     DVAE_TRY(g.nn(w.DA + (size_t)R * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)R * HP, HP, RH - R, HP, EHP));
-    if (k0_done) DVAE_CHECK_HIP(hipStreamWaitEvent(st, k0_done, 0));
   } else {
     DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
   }
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, R, HP, EHP, 1));
-  DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g));
+  DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, typed));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));

@@ -79,10 +79,11 @@ int k_chain_scatter(const SchedDir& Srev, const int* sizes, int B, int N, int t,
                     float* d_t, float* DHb, int HP, hipStream_t st);
 
 // type-shared prefix rows (sched.h TypeShare): TYPEV [32][HP] = GRU(one-hot c, h_in = 0);
-// DH[first row of type c in [r0,r1)] = T[c], DH[other rows] = 0  (rep: 32 ints of scratch)
+// backward: GH/GHN rows [r0,r1) zeroed, then the first row of each type gets the gate gradients of
+// the per-type sum T[c] = dL/dhv(type)  (rep: 32 ints of scratch)
 int k_type_states(int C, const GruW& w, float* TYPEV, int HP, hipStream_t st);
-int k_type_scatter(const int* row_type, int r0, int r1, const float* T, int* rep, float* DH, int HP,
-                   hipStream_t st);
+int k_type_gru_bwd(const int* row_type, int r0, int r1, int C, const GruW& w, const float* T, int* rep,
+                   float* GH, float* GHN, int HP, hipStream_t st);
 
 // decoder glue -----------------------------------------------------------------
 int k_graph_state_fwd(const SchedDir& S, int R, int N, int mod, const float* Hn, const float* h0, float* GS,

@@ -138,23 +138,53 @@ __global__ void type_states_kernel(int C, GruW w, float* __restrict__ TYPEV, int
   }
 }
 
-// rep[c] = first node row in [r0, r1) of type c (rep preset to INT_MAX)
-__global__ void type_rep_kernel(const int* __restrict__ row_type, int r0, int r1, int* __restrict__ rep) {
+// rep[c] = first node row in [r0, r1) of type c (rep preset to INT_MAX); block-local minimum
+// first, so the global atomics are 32 per block
+__global__ __launch_bounds__(256) void type_rep_kernel(const int* __restrict__ row_type, int r0, int r1,
+                                                       int* __restrict__ rep) {
+  __shared__ int loc[32];
+  if (threadIdx.x < 32) loc[threadIdx.x] = 0x7fffffff;
+  __syncthreads();
   for (int r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < r1; r += gridDim.x * blockDim.x)
-    atomicMin(rep + row_type[r], r);
+    atomicMin(loc + row_type[r], r);
+  __syncthreads();
+  if (threadIdx.x < 32 && loc[threadIdx.x] != 0x7fffffff) atomicMin(rep + threadIdx.x, loc[threadIdx.x]);
 }
 
-// The rows of one type share ONE state, so the gradient of that state is the per-type SUM T[c];
-// every per-row operation downstream is the same linear map for all rows of a type, hence the
-// sum is handed to the type's first row and the other rows get zero.
-__global__ void type_scatter_kernel(const int* __restrict__ row_type, const int* __restrict__ rep, int r0, int r1,
-                                    const float* __restrict__ T, float* __restrict__ DH, int HP) {
+// GRU backward of the type-shared rows.  All rows of a type have the same gates and h_in = 0, so
+// the per-row backward is one linear map per type and only the per-type SUM of dL/dhv matters
+// (T[c]): the type's first row receives the gate gradients of the sum, every other row of
+// [r0,r1) was zeroed by the caller.  Gates are recomputed from the weights (as type_states_kernel).
+__global__ void type_gru_bwd_kernel(int C, GruW w, const int* __restrict__ rep, const float* __restrict__ T,
+                                    float* __restrict__ GH, float* __restrict__ GHN, int HP) {
   const int HP4 = HP >> 2;
-  const long long total = (long long)(r1 - r0) * HP4;
+  const long long total = (long long)C * HP4;
   ITEM_LOOP(total) {
-    const int r = r0 + (int)(it / HP4), j = (int)(it % HP4) * 4;
-    const int c = row_type[r];
-    st4(DH + (size_t)r * HP + j, rep[c] == r ? ld4(T + (size_t)c * HP + j) : zero4());
+    const int c = (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int row = rep[c];
+    if (row == 0x7f7f7f7f) continue;   // no row of this type
+    float4 gi[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gi[g] = fma4(1.f, ld4(w.WihT + (size_t)c * 3 * HP + g * HP + j), ld4(w.bih + g * HP + j));
+    const float4 ghr = ld4(w.bhh + j), ghz = ld4(w.bhh + HP + j), ghn = ld4(w.bhh + 2 * HP + j);
+    const float4 dh = ld4(T + (size_t)c * HP + j);
+    float4 drp, dzp, dnp, dnr;
+#define TB_LANE(f)                                                          \
+    {                                                                       \
+      const float rr = sigm(gi[0].f + ghr.f), zz = sigm(gi[1].f + ghz.f);   \
+      const float nn = tanhf(gi[2].f + rr * ghn.f);                         \
+      dnp.f = dh.f * (1.f - zz) * (1.f - nn * nn);                          \
+      dzp.f = dh.f * (0.f - nn) * zz * (1.f - zz);                          \
+      drp.f = dnp.f * ghn.f * rr * (1.f - rr);                              \
+      dnr.f = dnp.f * rr;                                                   \
+    }
+    TB_LANE(x) TB_LANE(y) TB_LANE(z) TB_LANE(w)
+#undef TB_LANE
+    float* gh = GH + (size_t)row * 3 * HP;
+    st4(gh + j, drp);
+    st4(gh + HP + j, dzp);
+    st4(gh + 2 * HP + j, dnr);
+    st4(GHN + (size_t)row * HP + j, dnp);
   }
 }
 
@@ -345,22 +375,25 @@ __global__ void build_px_kernel(SchedDir S, int R, int npos, int PP, float* __re
   }
 }
 
-__global__ __launch_bounds__(64) void colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc,
-                                                    int W, float* __restrict__ part) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col >= W) return;
+// part[chunk][w] = sum over the chunk's rows of X[row][w]: a block owns 64 columns x one
+// row chunk; 16 row lanes x 16 float4 columns, rows strided by 16, lanes folded in fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc,
+                                                     int W, float* __restrict__ part) {
+  __shared__ float4 sh[16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + cx * 4;
   const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + col];
-  part[(size_t)blockIdx.y * W + col] = s;
-}
-
-// chunking: at most `maxc` chunks of at least 128 rows, bounded by the scratch
-inline void chunking(int rows, size_t per_chunk, size_t part_floats, int maxc, int* nch, int* rpc) {
-  int n = std::max(1, std::min(maxc, cdiv(rows, 32)));
-  if (per_chunk > 0) n = (int)std::max<size_t>(1, std::min<size_t>(n, part_floats / per_chunk));
-  *rpc = std::max(1, cdiv(rows, n));
-  *nch = std::max(1, cdiv(rows, *rpc));
+  float4 s = zero4();
+  if (col < W)
+    for (int r = r0 + ry; r < r1; r += 16) s = add4(s, ld4(X + (size_t)r * ld + col));
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < W) {
+    float4 t = sh[0][cx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t = add4(t, sh[k][cx]);
+    st4(part + (size_t)blockIdx.y * W + col, t);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -775,13 +808,15 @@ int k_type_states(int C, const GruW& w, float* TYPEV, int HP, hipStream_t st) {
   return DVAE_OK;
 }
 
-int k_type_scatter(const int* row_type, int r0, int r1, const float* T, int* rep, float* DH, int HP,
-                   hipStream_t st) {
+int k_type_gru_bwd(const int* row_type, int r0, int r1, int C, const GruW& w, const float* T, int* rep,
+                   float* GH, float* GHN, int HP, hipStream_t st) {
   if (r1 <= r0) return DVAE_OK;
   DVAE_CHECK_HIP(hipMemsetAsync(rep, 0x7f, 32 * sizeof(int), st));
-  hipLaunchKernelGGL(type_rep_kernel, grid_for(r1 - r0, 512), dim3(256), 0, st, row_type, r0, r1, rep);
-  hipLaunchKernelGGL(type_scatter_kernel, grid_for((long long)(r1 - r0) * (HP / 4)), dim3(256), 0, st, row_type,
-                     rep, r0, r1, T, DH, HP);
+  DVAE_CHECK_HIP(hipMemsetAsync(GH + (size_t)r0 * 3 * HP, 0, (size_t)(r1 - r0) * 3 * HP * sizeof(float), st));
+  DVAE_CHECK_HIP(hipMemsetAsync(GHN + (size_t)r0 * HP, 0, (size_t)(r1 - r0) * HP * sizeof(float), st));
+  hipLaunchKernelGGL(type_rep_kernel, grid_for(r1 - r0, 256), dim3(256), 0, st, row_type, r0, r1, rep);
+  hipLaunchKernelGGL(type_gru_bwd_kernel, grid_for((long long)C * (HP / 4)), dim3(256), 0, st, C, w, rep, T, GH,
+                     GHN, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
@@ -835,10 +870,15 @@ int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_
 
 int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
              hipStream_t st) {
-  int nch, rpc;
-  chunking(rows, (size_t)W, part_floats, 512, &nch, &rpc);
+  DVAE_REQUIRE((W & 3) == 0 && (ld & 3) == 0, "colsum: widths must be multiples of 4");
   DVAE_REQUIRE(part_floats >= (size_t)W, "colsum: scratch too small");
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(W, 64), nch), dim3(64), 0, st, X, ld, rows, rpc, W, part);
+  // enough chunks to fill the chip (column groups x chunks >= ~1024 blocks), at least 64 rows each
+  const int gx = cdiv(W, 64);
+  int nch = std::max(1, std::min(cdiv(1024, gx), cdiv(rows, 64)));
+  nch = (int)std::max<size_t>(1, std::min<size_t>(nch, part_floats / (size_t)W));
+  const int rpc = std::max(1, cdiv(rows, nch));
+  nch = std::max(1, cdiv(rows, rpc));
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, part);
   DVAE_LAUNCH_CHECK();
   return reduce_parts(part, nch, (size_t)W, out, (size_t)W, st);
 }
