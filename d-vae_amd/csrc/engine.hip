@@ -245,6 +245,14 @@ bool type_shared(const dvae_dims& d, const int* info, const Levels& lv) {
   return g_level_cfg.type_share && info[5] == 1 && d.mod == 0 && lv.nlev > 1 && lv.R > lv.ls[1];
 }
 
+// node rows that need a W1b product (Bq = W1b.hd + b1): all of them, minus the last level when it
+// holds exactly the last node of every graph (info[6]) -- a last node is never a candidate
+// predecessor (dvae_model.py:210 walks v_j < index only), so its Bq row is never read
+int bq_rows(const int* info, const Levels& lv) {
+  if (g_level_cfg.type_share && info[6] == 1 && lv.nlev > 0) return lv.ls[lv.nlev - 1];
+  return lv.R;
+}
+
 struct SweepW {
   GruW gru; const float* gm;   // gm: Wgm|posb (None) or WgmT|bgm (bn)
 };
@@ -563,11 +571,12 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     DVAE_TRY(gs.nt(w.TYPEV, HP, P + L.W1a, HP, w.AT, EHP, 32, EHP, HP));
     ts.AT = w.AT;
   }
+  const int Rb = bq_rows(info, lv);
   LevelHook hook = [&](int p0, int p1, int ns, int ne) -> int {
     DVAE_TRY(ev.edge(st, sd));
     DVAE_TRY(gs.nt(w.s.HV + (size_t)p0 * HP, HP, P + L.W1a, HP, w.A + (size_t)p0 * EHP, EHP, p1 - p0, EHP, HP));
-    DVAE_TRY(gs.nt(w.s.Hn + (size_t)ns * HP, HP, P + L.W1b, HP, w.Bq + (size_t)ns * EHP, EHP, ne - ns, EHP, HP,
-                   P + L.b1));
+    DVAE_TRY(gs.nt(w.s.Hn + (size_t)ns * HP, HP, P + L.W1b, HP, w.Bq + (size_t)ns * EHP, EHP,
+                   std::min(ne, Rb) - ns, EHP, HP, P + L.b1));
     return DVAE_OK;
   };
   DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g, hook, typed));
@@ -667,7 +676,8 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   } else {
     DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
   }
-  DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, R));
+  const int Rb = bq_rows(info, lv);   // DBq rows beyond Rb are zero (no pair has them as candidate)
+  DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, Rb));
   DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
   if (dgs_done) DVAE_CHECK_HIP(hipStreamWaitEvent(st, dgs_done, 0));
@@ -684,7 +694,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   } else {
     DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
   }
-  DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, R, HP, EHP, 1));
+  DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, Rb, HP, EHP, 1));
   DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, typed));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs));

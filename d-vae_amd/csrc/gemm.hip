@@ -372,7 +372,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   // split the reduction when the output alone cannot fill the chip (the
   // weight-gradient products: small [out][in] result, reduction over all rows)
   int splits = 1;
-  if (p.nblk < 256 && d.K >= 2048 && ws) {
+  if (p.nblk < 512 && d.K >= 2048 && ws) {
     static const int bulk_blocks = getenv("DVAE_BULK_BLOCKS") ? atoi(getenv("DVAE_BULK_BLOCKS")) : 768;   // tuning
     splits = min(cdiv(d.bulk ? bulk_blocks : g_splitk_blocks, p.nblk), d.K / 512);
   } else if (p.nblk <= 128 && d.K >= 512 && ws) {

@@ -336,11 +336,15 @@ __global__ void sched_info_kernel(SchedView s, int want_rev) {
   info[5] = info[6] = info[7] = 0;
 }
 
-// node type of every forward node row; err[1] counts rows whose encoding is not one-hot
+// node type of every forward node row; err[1] counts rows whose encoding is not one-hot,
+// err[2] rows for which "sits in the last level" and "is the last node of its graph" disagree
 __global__ void sched_types_kernel(SchedView s, const float* __restrict__ x, int C) {
-  const int R = s.dir[0].pos[(size_t)s.N * s.B];
+  const SchedDir& S = s.dir[0];
+  const int R = S.pos[(size_t)s.N * s.B];
+  const int last_level = s.info[3] - 1;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
-    const float* xr = x + ((size_t)s.dir[0].row_graph[r] * s.N + s.dir[0].row_node[r]) * C;
+    const int b = S.row_graph[r], i = S.row_node[r];
+    const float* xr = x + ((size_t)b * s.N + i) * C;
     int t = -1, ones = 0, other = 0;
     for (int c = 0; c < C; ++c) {
       const float v = xr[c];
@@ -349,11 +353,16 @@ __global__ void sched_types_kernel(SchedView s, const float* __restrict__ x, int
     }
     if (ones != 1 || other != 0) { t = -1; atomicAdd(s.err + 1, 1); }
     s.row_type[r] = t;
+    const bool last_node = i == s.N - 1 || S.node2row[b * s.N + i + 1] < 0;
+    if (last_node != (S.level[b * s.N + i] == last_level)) atomicAdd(s.err + 2, 1);
   }
 }
 
 __global__ void sched_types_info_kernel(SchedView s) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) s.info[5] = s.err[1] == 0 ? 1 : 0;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    s.info[5] = s.err[1] == 0 ? 1 : 0;
+    s.info[6] = s.err[2] == 0 ? 1 : 0;
+  }
 }
 
 }  // namespace
@@ -365,12 +374,12 @@ extern "C" int dvae_sched_types(const float* x, int B, int N, int C, void* sched
   DVAE_REQUIRE(B > 0 && N > 0 && N <= DVAE_MAX_N && C > 0 && C < DVAE_MAX_C, "sched_types: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   SchedView s = sched_view(sched, B, N);
-  DVAE_CHECK_HIP(hipMemsetAsync(s.err + 1, 0, sizeof(int), st));
+  DVAE_CHECK_HIP(hipMemsetAsync(s.err + 1, 0, 2 * sizeof(int), st));
   const int grid = std::min(cdiv(B * N, 256), 2048);
   hipLaunchKernelGGL(sched_types_kernel, dim3(grid), dim3(256), 0, st, s, x, C);
   hipLaunchKernelGGL(sched_types_info_kernel, dim3(1), dim3(64), 0, st, s);
   DVAE_LAUNCH_CHECK();
-  DVAE_CHECK_HIP(hipMemcpyAsync(info_host + 5, s.info + 5, sizeof(int), hipMemcpyDeviceToHost, st));
+  DVAE_CHECK_HIP(hipMemcpyAsync(info_host + 5, s.info + 5, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   return DVAE_OK;
 }
 

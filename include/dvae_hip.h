@@ -96,6 +96,8 @@ int dvae_gemm_profile_read(double* out12_host);
  *          [0] error flag (0 ok)   [1] R = valid nodes   [2] E = edges
  *          [3] forward level count [4] reverse level count
  *          [5] 1 after dvae_sched_types found every node encoding one-hot, else 0
+ *          [6] 1 after dvae_sched_types found that the last level holds exactly the last node of
+ *              every graph (true for chain-backed ENAS graphs), else 0
  *          [8 .. 8+N]        forward level starts (node rows), [8+nlev] = R
  *          [8+N+1 .. 8+2N+1] reverse level starts
  *          [8+2N+2 .. 8+3N+2] forward level starts in edge space (csr_ptr there)
@@ -109,7 +111,9 @@ int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_re
  * info_host[5] = 1 when every valid node's row is exactly one-hot.  The decoder then serves
  * the prefix rows whose GRU input is (type, h_in = 0) from a C-row table instead of
  * computing them per row (about a third of add_edge's first-layer work at ENAS sizes);
- * without this call, or with other encodings, every row is computed. */
+ * without this call, or with other encodings, every row is computed.  It also sets
+ * info_host[6] (see above): the last node of a graph is never a candidate predecessor, so its
+ * W1b product is skipped when those nodes form the (contiguous) last level. */
 int dvae_sched_types(const float* x, int B, int N, int C, void* sched, int* info_host, void* stream);
 /* copies one int32 array of the schedule to `out` (device); which:
  * 0 level_fwd[B*N] 1 level_rev[B*N] 2 node2row_fwd[B*N] 3 node2row_rev[B*N]
