@@ -211,7 +211,6 @@ class Dvae(nn.Module):
         self._shared_gm = bool(kw)
         self.beta = getattr(hparams, 'beta', 0.005)
         self._flat = None
-        self._side = None
         self._prep = None
 
     # -- reference API -------------------------------------------------------
