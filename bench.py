@@ -126,12 +126,15 @@ def main():
     # the level schedule of batch i+1 is queued (own stream) as soon as step i has been
     # launched, as a prefetching data loader would: every step still builds one schedule
     # inside the timed region, but nobody waits for its host round trip
+    # (multi-GPU runs build it in-step: with RCCL's streams a prefetch stream would be the fifth
+    # stream of the process and the box gives a process 4 hardware queues)
     prepared = {}
+    prefetch = not args.no_prefetch and dist is None
 
     def step(i):
         sched = prepared.pop(i, None)
         out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads, sched=sched)
-        if not args.no_prefetch:
+        if prefetch:
             prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True)
         opt.step()
         return out4
