@@ -656,9 +656,14 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const bool typed = type_shared(d, info, lv);
   const int z1 = lv.nlev > 0 ? lv.ls[1] : R;
   const TypeShare ts{typed ? w.AT : nullptr, z1};
-  DVAE_TRY(k_pair_bwd_a(sv, ts, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part,
-                        msc.part_floats, EHP, st));
-  DVAE_TRY(k_pair_bwd_b(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
+  if (pair_bwd_fused_ok(d.N, EHP)) {
+    DVAE_TRY(k_pair_bwd_fused(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.w2, msc.part,
+                              msc.part_floats, EHP, st));
+  } else {
+    DVAE_TRY(k_pair_bwd_a(sv, ts, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part,
+                          msc.part_floats, EHP, st));
+    DVAE_TRY(k_pair_bwd_b(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
+  }
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
   DVAE_TRY(ev.edge(st, sd));
   if (typed) {

@@ -98,6 +98,11 @@ int k_pair_bwd_a(const SchedView& sv, const TypeShare& ts, int R, int RH, const 
                  size_t part_floats, int EHP, hipStream_t st);
 int k_pair_bwd_b(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,
                  const float* Cq, const float* w2, const float* d_edge, float* DBq, int EHP, hipStream_t st);
+// both of the above in one pass, one workgroup per graph (small N only: pair_bwd_fused_ok)
+bool pair_bwd_fused_ok(int N, int EHP);
+int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A,
+                     const float* Bq, const float* Cq, const float* w2, const float* d_edge, float* DA, float* DBq,
+                     float* out, float* part, size_t part_floats, int EHP, hipStream_t st);
 // out[b] = sum over the graph's nodes of T[row]   (W % 4 == 0)
 int k_graph_sum(const SchedDir& S, const int* sizes, int B, int N, const float* T, int W, float* out,
                 hipStream_t st);

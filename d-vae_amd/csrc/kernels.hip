@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -766,6 +767,108 @@ __global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, TypeShare
   }
 }
 
+// Fused backward of the pair scorer for small graphs: one workgroup per graph walks the graph's
+// pairs once, in prefix-row order, and produces BOTH input gradients -- DA per prefix row (kept in
+// registers while the row's pairs pass) and DBq per candidate node (kept in LDS, [N][EHP], each
+// thread owning its columns, so no barrier is needed) -- plus the w2/b2 partials.  pair_bwd_a +
+// pair_bwd_b read every A and Bq row twice from HBM/L2 and recompute the ReLU mask twice.
+template <int VPL>
+__global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeShare ts, int R,
+                                                             const int* __restrict__ sizes,
+                                                             const float* __restrict__ A,
+                                                             const float* __restrict__ Bq,
+                                                             const float* __restrict__ Cq,
+                                                             const float* __restrict__ w2,
+                                                             const float* __restrict__ d_edge,
+                                                             float* __restrict__ DA, float* __restrict__ DBq,
+                                                             float* __restrict__ part) {
+  constexpr int EHP = VPL * 256, Q = VPL / 4;
+  static_assert(VPL % 4 == 0, "one float4 per thread per 1024 columns");
+  extern __shared__ __attribute__((aligned(16))) float dbq[];   // [N][EHP]
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N, B = sv.B;
+  const int col0 = threadIdx.x * 4;
+  float4 wv[Q], dw[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    wv[q] = ld4(w2 + col0 + 1024 * q);
+    dw[q] = zero4();
+  }
+  float db = 0.f;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const int n = graph_size(sizes, b, N);
+    for (int j = 0; j < n; ++j)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) st4(dbq + (size_t)j * EHP + col0 + 1024 * q, zero4());
+    float4 c[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) c[q] = Cq ? ld4(Cq + (size_t)b * EHP + col0 + 1024 * q) : zero4();
+    for (int i = 0; i < n; ++i) {
+      const int r = S.node2row[b * N + i];
+      const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+      int t = 0, cur = -1;
+      int next_pred = deg > 0 ? S.row_node[S.csr_idx[p]] : -1;
+      float4 a[Q], da[Q];
+      for (int j = i - 1; j >= 0; --j) {
+        while (t < deg && next_pred > j) {
+          ++t;
+          next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
+        }
+        if (t != cur) {
+          if (cur >= 0) {
+            float* dst = DA + (size_t)prow_of(S, R, r, cur) * EHP;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, da[q]);
+          }
+          const float* ar = a_row(sv, ts, A, EHP, R, r, t);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            a[q] = add4(ld4(ar + col0 + 1024 * q), c[q]);
+            da[q] = zero4();
+          }
+          cur = t;
+        }
+        const float ds = d_edge[((size_t)b * N + i) * N + j];
+        const float* bj = Bq + (size_t)S.node2row[b * N + j] * EHP;
+        float* dj = dbq + (size_t)j * EHP;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const float4 x = add4(a[q], ld4(bj + col0 + 1024 * q));
+          float4 g = ld4(dj + col0 + 1024 * q);
+#define PF_LANE(f)                                   \
+          if (x.f > 0.f) {                           \
+            const float u = ds * wv[q].f;            \
+            da[q].f += u;                            \
+            g.f += u;                                \
+            dw[q].f = fmaf(ds, x.f, dw[q].f);        \
+          }
+          PF_LANE(x) PF_LANE(y) PF_LANE(z) PF_LANE(w)
+#undef PF_LANE
+          st4(dj + col0 + 1024 * q, g);
+        }
+        db += ds;
+      }
+      // flush the last visited prefix row; rows without any pair (node 0's row, a final row whose
+      // lowest predecessor is node 0) get zeros
+      for (int k = 0; k <= deg; ++k) {
+        if (k < cur) continue;
+        float* dst = DA + (size_t)prow_of(S, R, r, k) * EHP;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, k == cur ? da[q] : zero4());
+      }
+    }
+    for (int j = 0; j < n; ++j) {
+      float* dst = DBq + (size_t)S.node2row[b * N + j] * EHP;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, ld4(dbq + (size_t)j * EHP + col0 + 1024 * q));
+    }
+  }
+  float* out = part + (size_t)blockIdx.x * (EHP + 4);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) st4(out + col0 + 1024 * q, dw[q]);
+  if (threadIdx.x == 0) st4(out + EHP, make_float4(db, 0.f, 0.f, 0.f));
+}
+
 #define VPL_DISPATCH(EHP, CALL)                                                   \
   switch ((EHP) / 256) {                                                          \
     case 1: { constexpr int V = 1; CALL; } break;                                 \
@@ -988,6 +1091,32 @@ int k_pair_bwd_a(const SchedView& sv, const TypeShare& ts, int R, int RH, const 
   // the scratch behind the per-wave partials holds the group sums of the two-stage reduction
   const size_t used = (size_t)grid * 4 * per;
   return reduce_parts_2stage(part, grid * 4, per, part + used, part_floats - used, out, per, st);
+}
+
+// true when k_pair_bwd_fused covers this shape (the DBq accumulators of a graph fit in 64 KB of LDS)
+bool pair_bwd_fused_ok(int N, int EHP) {
+  static const bool off = getenv("DVAE_NO_PAIR_FUSE") != nullptr;   // A-B tests
+  return !off && (EHP == 2048 || EHP == 1024 || EHP == 3072) && (size_t)N * EHP * sizeof(float) <= 65536;
+}
+
+int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A,
+                     const float* Bq, const float* Cq, const float* w2, const float* d_edge, float* DA, float* DBq,
+                     float* out, float* part, size_t part_floats, int EHP, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  const size_t per = (size_t)EHP + 4;
+  int grid = std::min(sv.B, 512);
+  grid = (int)std::min<size_t>(grid, part_floats / per);
+  DVAE_REQUIRE(grid >= 1, "pair_bwd_fused: scratch too small");
+  const size_t lds = (size_t)sv.N * EHP * sizeof(float);
+  switch (EHP / 256) {
+    case 4: hipLaunchKernelGGL((pair_bwd_fused_kernel<4>), dim3(grid), dim3(256), lds, st, sv, ts, R, sizes, A, Bq, Cq, w2, d_edge, DA, DBq, part); break;
+    case 8: hipLaunchKernelGGL((pair_bwd_fused_kernel<8>), dim3(grid), dim3(256), lds, st, sv, ts, R, sizes, A, Bq, Cq, w2, d_edge, DA, DBq, part); break;
+    case 12: hipLaunchKernelGGL((pair_bwd_fused_kernel<12>), dim3(grid), dim3(256), lds, st, sv, ts, R, sizes, A, Bq, Cq, w2, d_edge, DA, DBq, part); break;
+    default: dvae_set_error("pair_bwd_fused: width %d not instantiated", EHP); return DVAE_ERR_ARG;
+  }
+  DVAE_LAUNCH_CHECK();
+  const size_t used = (size_t)grid * per;
+  return reduce_parts_2stage(part, grid, per, part + used, part_floats - used, out, per, st);
 }
 
 int k_pair_bwd_b(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,
