@@ -769,10 +769,11 @@ __global__ __launch_bounds__(256) void pair_bwd_b_kernel(SchedView sv, TypeShare
 
 // Fused backward of the pair scorer for small graphs: one workgroup per graph walks the graph's
 // pairs once, in prefix-row order, and produces BOTH input gradients -- DA per prefix row (kept in
-// registers while the row's pairs pass) and DBq per candidate node (kept in LDS, [N][EHP], each
-// thread owning its columns, so no barrier is needed) -- plus the w2/b2 partials.  pair_bwd_a +
-// pair_bwd_b read every A and Bq row twice from HBM/L2 and recompute the ReLU mask twice.
-template <int VPL>
+// registers while the row's pairs pass) and DBq per candidate node (NREG > 0: in registers, for
+// graphs of up to NREG nodes; NREG = 0: in LDS, [N][EHP]; either way each thread owns its columns,
+// so no barrier is needed) -- plus the w2/b2 partials.  pair_bwd_a + pair_bwd_b read every A and
+// Bq row twice from HBM/L2 and recompute the ReLU mask twice.
+template <int VPL, int NREG>
 __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeShare ts, int R,
                                                              const int* __restrict__ sizes,
                                                              const float* __restrict__ A,
@@ -795,11 +796,20 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
     dw[q] = zero4();
   }
   float db = 0.f;
+  constexpr int NR = NREG > 0 ? NREG : 1;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const int n = graph_size(sizes, b, N);
-    for (int j = 0; j < n; ++j)
+    float4 dreg[NR][Q];
+    if (NREG > 0) {
 #pragma unroll
-      for (int q = 0; q < Q; ++q) st4(dbq + (size_t)j * EHP + col0 + 1024 * q, zero4());
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) dreg[j][q] = zero4();
+    } else {
+      for (int j = 0; j < n; ++j)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) st4(dbq + (size_t)j * EHP + col0 + 1024 * q, zero4());
+    }
     float4 c[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) c[q] = Cq ? ld4(Cq + (size_t)b * EHP + col0 + 1024 * q) : zero4();
@@ -809,7 +819,8 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
       int t = 0, cur = -1;
       int next_pred = deg > 0 ? S.row_node[S.csr_idx[p]] : -1;
       float4 a[Q], da[Q];
-      for (int j = i - 1; j >= 0; --j) {
+      // one pair (i,j): prefix row switch, ReLU mask, the three gradient accumulations
+      auto pair = [&](int j, float4* dj) {
         while (t < deg && next_pred > j) {
           ++t;
           next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
@@ -830,23 +841,34 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
         }
         const float ds = d_edge[((size_t)b * N + i) * N + j];
         const float* bj = Bq + (size_t)S.node2row[b * N + j] * EHP;
-        float* dj = dbq + (size_t)j * EHP;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
           const float4 x = add4(a[q], ld4(bj + col0 + 1024 * q));
-          float4 g = ld4(dj + col0 + 1024 * q);
 #define PF_LANE(f)                                   \
           if (x.f > 0.f) {                           \
             const float u = ds * wv[q].f;            \
             da[q].f += u;                            \
-            g.f += u;                                \
+            dj[q].f += u;                            \
             dw[q].f = fmaf(ds, x.f, dw[q].f);        \
           }
           PF_LANE(x) PF_LANE(y) PF_LANE(z) PF_LANE(w)
 #undef PF_LANE
-          st4(dj + col0 + 1024 * q, g);
         }
         db += ds;
+      };
+      if (NREG > 0) {
+#pragma unroll
+        for (int j = NR - 2; j >= 0; --j)
+          if (j < i) pair(j, dreg[j]);
+      } else {
+        for (int j = i - 1; j >= 0; --j) {
+          float4 g[Q];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) g[q] = ld4(dbq + (size_t)j * EHP + col0 + 1024 * q);
+          pair(j, g);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) st4(dbq + (size_t)j * EHP + col0 + 1024 * q, g[q]);
+        }
       }
       // flush the last visited prefix row; rows without any pair (node 0's row, a final row whose
       // lowest predecessor is node 0) get zeros
@@ -857,10 +879,20 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
         for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, k == cur ? da[q] : zero4());
       }
     }
-    for (int j = 0; j < n; ++j) {
-      float* dst = DBq + (size_t)S.node2row[b * N + j] * EHP;
+    if (NREG > 0) {
 #pragma unroll
-      for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, ld4(dbq + (size_t)j * EHP + col0 + 1024 * q));
+      for (int j = 0; j < NR; ++j)
+        if (j < n) {
+          float* dst = DBq + (size_t)S.node2row[b * N + j] * EHP;
+#pragma unroll
+          for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, dreg[j][q]);
+        }
+    } else {
+      for (int j = 0; j < n; ++j) {
+        float* dst = DBq + (size_t)S.node2row[b * N + j] * EHP;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, ld4(dbq + (size_t)j * EHP + col0 + 1024 * q));
+      }
     }
   }
   float* out = part + (size_t)blockIdx.x * (EHP + 4);
@@ -1096,7 +1128,7 @@ int k_pair_bwd_a(const SchedView& sv, const TypeShare& ts, int R, int RH, const 
 // true when k_pair_bwd_fused covers this shape (the DBq accumulators of a graph fit in 64 KB of LDS)
 bool pair_bwd_fused_ok(int N, int EHP) {
   static const bool off = getenv("DVAE_NO_PAIR_FUSE") != nullptr;   // A-B tests
-  return !off && (EHP == 2048 || EHP == 1024 || EHP == 3072) && (size_t)N * EHP * sizeof(float) <= 65536;
+  return !off && (EHP == 2048 || EHP == 1024 || EHP == 3072) && (N <= 8 || (size_t)N * EHP * sizeof(float) <= 65536);
 }
 
 int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A,
@@ -1107,13 +1139,26 @@ int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int*
   int grid = std::min(sv.B, 512);
   grid = (int)std::min<size_t>(grid, part_floats / per);
   DVAE_REQUIRE(grid >= 1, "pair_bwd_fused: scratch too small");
-  const size_t lds = (size_t)sv.N * EHP * sizeof(float);
+  // up to 8 nodes: DBq accumulators in registers (no LDS, more workgroups per CU); else in LDS
+  static const bool force_lds = getenv("DVAE_PAIR_LDS") != nullptr;   // lab: same-box A-B
+  const bool reg = sv.N <= 8 && !force_lds;
+  const size_t lds = reg ? 0 : (size_t)sv.N * EHP * sizeof(float);
+  grid = std::min(sv.B, reg ? 1024 : 512);
+  grid = (int)std::min<size_t>(grid, part_floats / per);
+#define PAIR_FUSED(V)                                                                                          \
+  if (reg)                                                                                                     \
+    hipLaunchKernelGGL((pair_bwd_fused_kernel<V, 8>), dim3(grid), dim3(256), 0, st, sv, ts, R, sizes, A, Bq, Cq, \
+                       w2, d_edge, DA, DBq, part);                                                             \
+  else                                                                                                         \
+    hipLaunchKernelGGL((pair_bwd_fused_kernel<V, 0>), dim3(grid), dim3(256), lds, st, sv, ts, R, sizes, A, Bq, \
+                       Cq, w2, d_edge, DA, DBq, part)
   switch (EHP / 256) {
-    case 4: hipLaunchKernelGGL((pair_bwd_fused_kernel<4>), dim3(grid), dim3(256), lds, st, sv, ts, R, sizes, A, Bq, Cq, w2, d_edge, DA, DBq, part); break;
-    case 8: hipLaunchKernelGGL((pair_bwd_fused_kernel<8>), dim3(grid), dim3(256), lds, st, sv, ts, R, sizes, A, Bq, Cq, w2, d_edge, DA, DBq, part); break;
-    case 12: hipLaunchKernelGGL((pair_bwd_fused_kernel<12>), dim3(grid), dim3(256), lds, st, sv, ts, R, sizes, A, Bq, Cq, w2, d_edge, DA, DBq, part); break;
+    case 4: PAIR_FUSED(4); break;
+    case 8: PAIR_FUSED(8); break;
+    case 12: PAIR_FUSED(12); break;
     default: dvae_set_error("pair_bwd_fused: width %d not instantiated", EHP); return DVAE_ERR_ARG;
   }
+#undef PAIR_FUSED
   DVAE_LAUNCH_CHECK();
   const size_t used = (size_t)grid * per;
   return reduce_parts_2stage(part, grid, per, part + used, part_floats - used, out, per, st);
