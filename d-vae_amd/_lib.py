@@ -130,4 +130,4 @@ def make_dims(B, N, C, H, Z, mod, bidir, npos):
 
 
 def sched_info_ints(N):
-    return 8 + 3 * (N + 1)
+    return 8 + 4 * (N + 1)

@@ -59,6 +59,8 @@ struct GemmDesc {
   int prio;            // 1: waves run at raised priority (launches on the per-level chain)
   int bulk;            // 1: side-stream product: a split-K launch takes ONE workgroup per CU, so
                        //    that chain launches arriving later still find free slots on every CU
+  const int* row_map;  // optional (m-major A only): row m of the product reads A row row_map[m] and
+                       // writes C row row_map[m] -- a product over a scattered subset of rows
 };
 // C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);

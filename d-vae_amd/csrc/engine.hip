@@ -189,14 +189,14 @@ struct G {
   float* ws; hipStream_t st; int prio = 0; int bulk = 0;
   // Y[M][N] (+)= X[M][K] W[N][K]^T + bias
   int nt(const float* X, int ldx, const float* W, int ldw, float* Y, int ldy, int M, int N, int K,
-         const float* bias = nullptr, int relu = 0, int acc = 0) const {
-    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio, bulk};
+         const float* bias = nullptr, int relu = 0, int acc = 0, const int* rows = nullptr) const {
+    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio, bulk, rows};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dX[M][N] (+)= dY[M][K] W[K][N]
   int nn(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K,
-         int acc = 0) const {
-    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio, bulk};
+         int acc = 0, const int* rows = nullptr) const {
+    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio, bulk, rows};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dW[M][N] (+)= dY[K][M]^T X[K][N]   (K = rows)
@@ -210,7 +210,7 @@ struct G {
       }
       return DVAE_OK;
     }
-    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc, prio, bulk};
+    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc, prio, bulk, nullptr};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
 };
@@ -219,6 +219,14 @@ struct Levels {
   int R, E, nlev;
   const int* ls;   // node-row level starts [nlev+1]
   const int* es;   // edge-space level starts (forward only)
+  const int* as;   // the same in scored edge rows (SchedView::a_rows)
+  int N;
+  // scored edge rows before edge-space position e, which must be a level start
+  int scored_before(int e) const {
+    for (int L = 0; L <= N; ++L)
+      if (es[L] == e) return as[L];
+    return -1;
+  }
 };
 
 Levels levels_of(const dvae_dims& d, const int* info, int dir) {
@@ -226,6 +234,8 @@ Levels levels_of(const dvae_dims& d, const int* info, int dir) {
   l.R = info[1]; l.E = info[2]; l.nlev = info[3 + dir];
   l.ls = info + 8 + dir * (d.N + 1);
   l.es = info + 8 + 2 * (d.N + 1);
+  l.as = info + 8 + 3 * (d.N + 1);
+  l.N = d.N;
   return l;
 }
 
@@ -252,6 +262,16 @@ int bq_rows(const int* info, const Levels& lv) {
   if (g_level_cfg.type_share && info[6] == 1 && lv.nlev > 0) return lv.ls[lv.nlev - 1];
   return lv.R;
 }
+
+// add_edge's first layer A = W1a.hv is read on the prefixes some pair is scored on only
+// (SchedView::a_rows): the other edge rows -- and node 0's row, which has no pair at all, when
+// level 0 holds nothing else (info[7]) -- take no W1a product, forward or backward.
+// DVAE_NO_ROW_SKIP=1: every row (A-B tests).
+bool scored_rows_only() {
+  static const bool off = getenv("DVAE_NO_ROW_SKIP") != nullptr;
+  return g_level_cfg.type_share && !off;
+}
+bool skip_level0(const int* info) { return scored_rows_only() && info[7] == 1; }
 
 struct SweepW {
   GruW gru; const float* gm;   // gm: Wgm|posb (None) or WgmT|bgm (bn)
@@ -572,9 +592,22 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     ts.AT = w.AT;
   }
   const int Rb = bq_rows(info, lv);
+  const bool scored = scored_rows_only(), skip0 = skip_level0(info);
   LevelHook hook = [&](int p0, int p1, int ns, int ne) -> int {
     DVAE_TRY(ev.edge(st, sd));
-    DVAE_TRY(gs.nt(w.s.HV + (size_t)p0 * HP, HP, P + L.W1a, HP, w.A + (size_t)p0 * EHP, EHP, p1 - p0, EHP, HP));
+    // k = 0 rows, then edge rows
+    const int n0 = (skip0 && p0 == 0) ? std::min(z1, p1) : p0, n1 = std::min(p1, R);
+    if (n1 > n0)
+      DVAE_TRY(gs.nt(w.s.HV + (size_t)n0 * HP, HP, P + L.W1a, HP, w.A + (size_t)n0 * EHP, EHP, n1 - n0, EHP, HP));
+    const int e0 = std::max(p0, R), e1 = p1;
+    if (e1 > e0) {
+      const int u0 = scored ? lv.scored_before(e0 - R) : -1, u1 = scored ? lv.scored_before(e1 - R) : -1;
+      if (u0 >= 0 && u1 >= u0) {
+        DVAE_TRY(gs.nt(w.s.HV, HP, P + L.W1a, HP, w.A, EHP, u1 - u0, EHP, HP, nullptr, 0, 0, sv.a_rows + u0));
+      } else {
+        DVAE_TRY(gs.nt(w.s.HV + (size_t)e0 * HP, HP, P + L.W1a, HP, w.A + (size_t)e0 * EHP, EHP, e1 - e0, EHP, HP));
+      }
+    }
     DVAE_TRY(gs.nt(w.s.Hn + (size_t)ns * HP, HP, P + L.W1b, HP, w.Bq + (size_t)ns * EHP, EHP,
                    std::min(ne, Rb) - ns, EHP, HP, P + L.b1));
     return DVAE_OK;
@@ -656,6 +689,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const bool typed = type_shared(d, info, lv);
   const int z1 = lv.nlev > 0 ? lv.ls[1] : R;
   const TypeShare ts{typed ? w.AT : nullptr, z1};
+  const bool scored = scored_rows_only(), skip0 = skip_level0(info);
   if (pair_bwd_fused_ok(d.N, EHP)) {
     DVAE_TRY(k_pair_bwd_fused(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.w2, msc.part,
                               msc.part_floats, EHP, st));
@@ -675,8 +709,8 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
     DVAE_TRY(k_type_gru_bwd(sv.row_type, z1, R, d.C, sw.gru, w.DTV, reinterpret_cast<int*>(w.REP), w.s.GH, w.s.GHN,
                             HP, sd));
-    DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1));
-    DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R, 1));
+    DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R));
+    if (!skip0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1, 1));
     DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
   } else {
     DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
@@ -693,11 +727,21 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   // (measured and dropped: producing dA.W1a / dBq.W1b level by level just ahead of the sweep and
   // issuing the sweep's weight-gradient products level by level behind it -- the smaller launches
   // cost more than the earlier start and the shorter tail gave: +0.5 ms at B=4096)
-  if (typed) {
-    DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, z1, HP, EHP));
-    DVAE_TRY(g.nn(w.DA + (size_t)R * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)R * HP, HP, RH - R, HP, EHP));
-  } else {
-    DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, RH, HP, EHP));
+  {
+    // k = 0 rows: level 0 (unless it holds node 0 only, which no pair is scored on), and the later
+    // levels when they are not shared by type
+    const int n0 = skip0 ? z1 : 0, n1 = typed ? z1 : R;
+    if (n0 > 0) DVAE_CHECK_HIP(hipMemsetAsync(w.s.DH, 0, (size_t)n0 * HP * 4, st));
+    if (n1 > n0)
+      DVAE_TRY(g.nn(w.DA + (size_t)n0 * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)n0 * HP, HP, n1 - n0, HP, EHP));
+    // edge rows: the scored ones, zeros in the others
+    const int U = scored ? lv.as[d.N] : -1;
+    if (U >= 0 && U <= lv.E) {
+      DVAE_TRY(k_zero_rows(w.s.DH, HP, HP, sv.a_skip, lv.E - U, st));
+      DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, U, HP, EHP, 0, sv.a_rows));
+    } else {
+      DVAE_TRY(g.nn(w.DA + (size_t)R * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)R * HP, HP, RH - R, HP, EHP));
+    }
   }
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, Rb, HP, EHP, 1));
   DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, typed));

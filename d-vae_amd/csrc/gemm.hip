@@ -45,6 +45,19 @@ struct Tile {
   static_assert(NV >= 1, "tile too small for 256 threads");
   static constexpr int LDS_FLOATS = KM ? BK * ROWS : ROWS * LDM;
   float4 v[NV];
+  size_t ro[NV];   // m-major: float offset of this thread's row(s), fixed over the k loop
+
+  // m-major operand: where this thread's rows start; `map` (optional) sends row r of the
+  // product to row map[r] of the operand (row gather).  Rows beyond `rows` clamp to the last one.
+  __device__ __forceinline__ void rows_init(int ld, int r0, int rows, const int* __restrict__ map, int tid) {
+    if (KM == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int r = min(r0 + tid / KQ + i * (256 / KQ), rows - 1);
+        ro[i] = (size_t)(map ? map[r] : r) * ld;
+      }
+    }
+  }
 
   // rows: extent of the non-reduction dim; kend: end of this block's k range.
   // CHECK = false: the caller guarantees that the k range [k0, k0+BK) lies inside the
@@ -56,10 +69,7 @@ struct Tile {
     if (!CHECK) {
       if (KM == 0) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const int r = min(r0 + tid / KQ + i * (256 / KQ), rows - 1);
-          v[i] = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k0 + (tid % KQ) * 4);
-        }
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(P + ro[i] + k0 + (tid % KQ) * 4);
       } else {
         constexpr int RQ = ROWS / 4;
         const int r = min(r0 + (tid % RQ) * 4, rows - 4);
@@ -77,7 +87,7 @@ struct Tile {
       if (KM == 0) {
         const int row = idx / KQ, kq = idx % KQ;
         const int r = r0 + row, k = k0 + kq * 4;
-        if (r < rows && k < kend) val = *reinterpret_cast<const float4*>(P + (size_t)r * ld + k);
+        if (r < rows && k < kend) val = *reinterpret_cast<const float4*>(P + ro[i] + k);
       } else {
         constexpr int RQ = ROWS / 4;
         const int kr = idx / RQ, rq = idx % RQ;
@@ -126,6 +136,7 @@ struct GemmParams {
   int tiles_n, nblk;
   int dbg;                // lab only
   int prio;               // wave priority (s_setprio): the per-level chain outranks the bulk side-stream products
+  const int* row_map;     // optional: row m of the product reads A row row_map[m] and writes C row row_map[m]
 };
 
 // bijective XCD-aware remap: blocks that share blockIdx%8 (one XCD under
@@ -173,6 +184,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
 
   TA ta;
   TB tb;
+  ta.rows_init(p.lda, m0, p.M, AKM == 0 ? p.row_map : nullptr, tid);
+  tb.rows_init(p.ldb, n0, p.N, nullptr, tid);
   ta.template load<true>(p.A, p.lda, m0, p.M, kb, ke, tid);
   tb.template load<true>(p.B, p.ldb, n0, p.N, kb, ke, tid);
   ta.store(lds, tid);
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   for (int i = 0; i < TM; ++i) {
     const int row = m0 + wm * (BM / WM) + i * 32 + (lane & 31);
     if (row >= p.M) continue;
-    float* crow = C + (size_t)row * p.ldc;
+    float* crow = C + (size_t)(p.row_map ? p.row_map[row] : row) * p.ldc;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -365,6 +378,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   p.relu = d.relu; p.accumulate = d.accumulate;
   p.prio = g_force_prio >= 0 ? g_force_prio : d.prio;
   p.dbg = g_dbg;
+  p.row_map = d.row_map;
   const int tiles_m = cdiv(d.M, BM);
   p.tiles_n = cdiv(d.N, BN);
   p.nblk = tiles_m * p.tiles_n;
@@ -380,6 +394,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     // loop at one workgroup per CU, is latency-bound -- spread K over the idle CUs
     splits = min(cdiv(256, p.nblk), d.K / 128);
   }
+  if (d.row_map) splits = 1;   // the slab reduction does not scatter rows
   if (splits > 1) {
     const size_t slab = (size_t)d.M * d.N * sizeof(float);
     if (slab == 0) return DVAE_OK;
@@ -422,6 +437,7 @@ extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0) return DVAE_OK;
   DVAE_REQUIRE(d.K > 0, "gemm: K must be positive");
+  DVAE_REQUIRE(!d.row_map || !d.a_kmajor, "gemm: a row map needs an m-major A");
   DVAE_REQUIRE(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0, "gemm: operands must be 16-byte aligned");
   DVAE_REQUIRE((d.lda & 3) == 0 && (d.ldb & 3) == 0, "gemm: leading dimensions must be multiples of 4");
   // the contiguous extent of every operand is loaded as float4
@@ -473,7 +489,7 @@ extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float*
   d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
   d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
   d.bias = bias; d.relu = relu; d.accumulate = accumulate;
-  d.prio = 0; d.bulk = 0;
+  d.prio = 0; d.bulk = 0; d.row_map = nullptr;
   return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
 }
 

@@ -113,5 +113,6 @@ int k_add_dh0(const SchedDir& S, int B, int N, const float* DAGG, float* dh0, in
 // out[r][c] = c < W ? in[r][c] : 0 for c < ncols (in == NULL: zeros)
 int k_pad_rows(const float* in, int rows, int W, float* out, int ld, int ncols, hipStream_t st);
 int k_relu_bwd(float* d, const float* y, size_t n, hipStream_t st);   // d *= (y > 0)
+int k_zero_rows(float* X, int ld, int W, const int* rows, int n, hipStream_t st);   // X[rows[i]][0..W) = 0
 int k_unpad_rows(const float* in, int ld, int rows, int W, float* out, hipStream_t st);
 int k_add_rows(float* dst, int ldd, const float* src, int lds_, int rows, int W, hipStream_t st);

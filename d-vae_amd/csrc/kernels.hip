@@ -574,6 +574,16 @@ __global__ void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__
     if (!(y[i] > 0.f)) d[i] = 0.f;
 }
 
+// X[rows[i]][0..W) = 0 (W a multiple of 4)
+__global__ void zero_rows_kernel(float* __restrict__ X, int ld, int W, const int* __restrict__ rows, int n) {
+  const int wq = W >> 2;
+  const long long total = (long long)n * wq;
+  ITEM_LOOP(total) {
+    const int i = (int)(it / wq), q = (int)(it % wq);
+    st4(X + (size_t)rows[i] * ld + q * 4, zero4());
+  }
+}
+
 __global__ void unpad_rows_kernel(const float* __restrict__ in, int ld, int rows, int W, float* __restrict__ out) {
   const long long total = (long long)rows * W;
   ITEM_LOOP(total) {
@@ -1199,6 +1209,13 @@ int k_pad_rows(const float* in, int rows, int W, float* out, int ld, int ncols, 
 int k_relu_bwd(float* d, const float* y, size_t n, hipStream_t st) {
   if (n == 0) return DVAE_OK;
   hipLaunchKernelGGL(relu_bwd_kernel, grid_for((long long)n), dim3(256), 0, st, d, y, n);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_zero_rows(float* X, int ld, int W, const int* rows, int n, hipStream_t st) {
+  if (n <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(zero_rows_kernel, grid_for((long long)n * (W / 4)), dim3(256), 0, st, X, ld, W, rows, n);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }

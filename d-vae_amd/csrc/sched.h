@@ -25,11 +25,16 @@ struct SchedView {
   int B, N, RM, EM;
   uint32_t* rowbits;  // [B*N*4] bit u of row i set <=> edge u->i
   uint32_t* colbits;  // [B*N*4] bit u of row i set <=> edge i->u
-  int* err;           // [1]
+  int* err;           // [64] 0: invalid adjacency, 1-2: dvae_sched_types, 3: level 0 holds a node other than node 0
   int* scan_tmp;      // tile sums for the scan
   int* info;          // [DVAE_SCHED_INFO_INTS(N)] device copy of info_host
   int* row_type;      // [RM] forward node row -> node type if its encoding is exactly one-hot,
                       //      else -1 (filled by dvae_sched_types; info[5] = 1 when every row has one)
+  int* a_pos;         // [EM+1] scored edge rows before edge e (exclusive scan)
+  int* a_rows;        // [EM] the decoder's edge prefix rows that add_edge scores, ascending: every
+                      //      edge row except a node's FULL prefix when node 0 is among its predecessors
+                      //      (the last pair of such a node, (i,0), is scored before edge 0 is added)
+  int* a_skip;        // [EM] the other edge rows, ascending
   SchedDir dir[2];    // 0 forward, 1 reverse
 };
 

@@ -35,6 +35,9 @@ SchedView carve(void* base, int B, int N, size_t* total) {
   v.scan_tmp = c.take<int>((size_t)cdiv(v.RM + N + 2, SCAN_TILE) + 64);
   v.info = c.take<int>(DVAE_SCHED_INFO_INTS(N));
   v.row_type = c.take<int>(v.RM);
+  v.a_pos = c.take<int>((size_t)v.EM + 1);
+  v.a_rows = c.take<int>(v.EM);
+  v.a_skip = c.take<int>(v.EM);
   for (int d = 0; d < 2; ++d) {
     SchedDir& s = v.dir[d];
     s.level = c.take<int>(v.RM);
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(64) void sched_assign_kernel(SchedView s, int d) {
       }
       S.csr_ptr[row] = deg;   // scanned in place afterwards
       S.csc_ptr[row] = out;
+      if (d == 0 && L == 0 && i != 0) atomicOr(s.err + 3, 1);   // a source other than node 0
     }
     S.node2row[b * N + i] = row;
   }
@@ -272,6 +276,9 @@ __global__ __launch_bounds__(64) void sched_fill_kernel(SchedView s, int d) {
       const int R = S.pos[(size_t)s.N * s.B];
       S.prow_node[row] = row;
       for (int k = 0; k < deg; ++k) S.prow_node[R + S.csr_ptr[row] + k] = row;
+      // add_edge scores pair (i, j) on the prefix that holds the predecessors above j
+      // (dvae_model.py:210-220): the full prefix is scored only when node 0 is not a predecessor
+      for (int k = 0; k < deg; ++k) s.a_pos[S.csr_ptr[row] + k] = (k == deg - 1 && (pm[0] & 1u)) ? 0 : 1;
     }
     // successors of node i, ascending index
     const uint32_t* sm = succb + ((size_t)b * N + i) * DVAE_BITW;
@@ -305,6 +312,17 @@ __global__ __launch_bounds__(64) void sched_fill_kernel(SchedView s, int d) {
   }
 }
 
+// scored edge rows in ascending order -> a_rows, the others -> a_skip (a_pos: exclusive scan of the flags)
+__global__ void sched_scored_kernel(SchedView s) {
+  const int R = s.dir[0].pos[(size_t)s.N * s.B];
+  const int E = s.dir[0].csr_ptr[s.RM];
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    const int q = s.a_pos[e];
+    if (s.a_pos[e + 1] != q) s.a_rows[q] = R + e;
+    else s.a_skip[e - q] = R + e;
+  }
+}
+
 __global__ void sched_info_kernel(SchedView s, int want_rev) {
   // single thread: tiny
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -333,7 +351,11 @@ __global__ void sched_info_kernel(SchedView s, int want_rev) {
   // that decoder prefix rows of level L are [ls[L]+es[L], ls[L+1]+es[L+1])
   int* es = info + 8 + 2 * (N + 1);
   for (int L = 0; L <= N; ++L) es[L] = s.dir[0].csr_ptr[info[8 + L]];
-  info[5] = info[6] = info[7] = 0;
+  // the same starts counted in scored edge rows only (a_rows)
+  int* as = info + 8 + 3 * (N + 1);
+  for (int L = 0; L <= N; ++L) as[L] = s.a_pos[es[L]];
+  info[5] = info[6] = 0;
+  info[7] = s.err[3] == 0 ? 1 : 0;
 }
 
 // node type of every forward node row; err[1] counts rows whose encoding is not one-hot,
@@ -398,6 +420,8 @@ extern "C" int dvae_sched_build(const float* g, const int* sizes, int B, int N, 
   hipStream_t st = (hipStream_t)stream;
   SchedView s = sched_view(sched, B, N);
   DVAE_CHECK_HIP(hipMemsetAsync(s.err, 0, sizeof(int), st));
+  DVAE_CHECK_HIP(hipMemsetAsync(s.err + 3, 0, sizeof(int), st));
+  DVAE_CHECK_HIP(hipMemsetAsync(s.a_pos, 0, sizeof(int) * ((size_t)s.EM + 1), st));
   hipLaunchKernelGGL(sched_levels_kernel, dim3(B), dim3(64), 0, st, g, sizes, s, want_reverse);
   DVAE_LAUNCH_CHECK();
   for (int d = 0; d < (want_reverse ? 2 : 1); ++d) {
@@ -412,6 +436,11 @@ extern "C" int dvae_sched_build(const float* g, const int* sizes, int B, int N, 
     DVAE_TRY(exclusive_scan(S.csc_ptr, S.csc_ptr, s.RM, s.scan_tmp, st));
     hipLaunchKernelGGL(sched_fill_kernel, dim3(B), dim3(64), 0, st, s, d);
     DVAE_LAUNCH_CHECK();
+    if (d == 0) {
+      DVAE_TRY(exclusive_scan(s.a_pos, s.a_pos, s.EM, s.scan_tmp, st));
+      hipLaunchKernelGGL(sched_scored_kernel, dim3(std::min(cdiv(s.EM, 256), 1024)), dim3(256), 0, st, s);
+      DVAE_LAUNCH_CHECK();
+    }
   }
   hipLaunchKernelGGL(sched_info_kernel, dim3(1), dim3(64), 0, st, s, want_reverse);
   DVAE_LAUNCH_CHECK();
@@ -434,6 +463,8 @@ extern "C" int dvae_sched_export(const void* sched, int B, int N, int which, int
     case 5: src = s.dir[0].csr_idx; n = s.EM; break;
     case 6: src = s.dir[0].row_graph; n = s.RM; break;
     case 7: src = s.dir[0].row_node; n = s.RM; break;
+    case 8: src = s.a_rows; n = s.EM; break;
+    case 9: src = s.a_skip; n = s.EM; break;
     default: dvae_set_error("sched_export: unknown array %d", which); return DVAE_ERR_ARG;
   }
   if (n > max_ints) n = max_ints;

@@ -98,11 +98,16 @@ int dvae_gemm_profile_read(double* out12_host);
  *          [5] 1 after dvae_sched_types found every node encoding one-hot, else 0
  *          [6] 1 after dvae_sched_types found that the last level holds exactly the last node of
  *              every graph (true for chain-backed ENAS graphs), else 0
+ *          [7] 1 when level 0 holds node 0 of every graph and nothing else (no other source node)
  *          [8 .. 8+N]        forward level starts (node rows), [8+nlev] = R
  *          [8+N+1 .. 8+2N+1] reverse level starts
  *          [8+2N+2 .. 8+3N+2] forward level starts in edge space (csr_ptr there)
+ *          [8+3N+3 .. 8+4N+3] the same starts counted in SCORED edge rows only: the decoder's
+ *              prefix rows that add_edge reads (dvae_model.py:210-220 scores pair (i,j) on the
+ *              prefix holding the predecessors above j, so a node's full prefix is read only
+ *              when node 0 is not among its predecessors)
  * ---------------------------------------------------------------------- */
-#define DVAE_SCHED_INFO_INTS(N) (8 + 3 * ((N) + 1))
+#define DVAE_SCHED_INFO_INTS(N) (8 + 4 * ((N) + 1))
 size_t dvae_sched_bytes(int B, int N);
 int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_reverse, void* sched,
                      int* info_host, void* stream);
@@ -117,7 +122,8 @@ int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_re
 int dvae_sched_types(const float* x, int B, int N, int C, void* sched, int* info_host, void* stream);
 /* copies one int32 array of the schedule to `out` (device); which:
  * 0 level_fwd[B*N] 1 level_rev[B*N] 2 node2row_fwd[B*N] 3 node2row_rev[B*N]
- * 4 csr_ptr_fwd[R+1] 5 csr_idx_fwd[E] 6 row_graph_fwd[R] 7 row_node_fwd[R] */
+ * 4 csr_ptr_fwd[R+1] 5 csr_idx_fwd[E] 6 row_graph_fwd[R] 7 row_node_fwd[R]
+ * 8 scored edge prefix rows (R + edge index, ascending) 9 the unscored ones */
 int dvae_sched_export(const void* sched, int B, int N, int which, int* out, size_t max_ints,
                       void* stream);
 

@@ -118,6 +118,24 @@ def test_schedule_bit_exact(cuda, B, N, p, ragged):
             r = n2r[b, i]
             got = idx[ptr[r]:ptr[r + 1]].tolist()
             assert got == [n2r[b, u] for u in preds[b][i]]
+    # scored / unscored edge prefix rows: add_edge scores pair (i, j) on the prefix holding the
+    # predecessors above j (dvae_model.py:210-220), so the full prefix of a node (its last edge
+    # row) is read only when node 0 is not among its predecessors
+    scored, skipped = [], []
+    for r in range(R):
+        b, i = order[r][1], order[r][2]
+        for k in range(ptr[r], ptr[r + 1]):
+            last = k == ptr[r + 1] - 1
+            (skipped if last and 0 in preds[b][i] else scored).append(R + k)
+    if s.E:
+        assert s.export(8, s.E).cpu().numpy()[:len(scored)].tolist() == scored
+        assert s.export(9, s.E).cpu().numpy()[:len(skipped)].tolist() == skipped
+    es = s.info[8 + 2 * (N + 1):8 + 3 * (N + 1)]
+    cs = s.info[8 + 3 * (N + 1):8 + 4 * (N + 1)]
+    for L in range(N + 1):
+        assert cs[L] == sum(1 for p in scored if p - R < es[L])
+    sources_are_node0 = all(o[2] == 0 for o in order if o[0] == 0)
+    assert int(s.info[7]) == int(sources_are_node0)
 
 
 def test_schedule_rejects_bad_graph(cuda):
