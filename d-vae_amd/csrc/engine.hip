@@ -118,7 +118,7 @@ struct DecWs {
   float *ZPAD, *H0, *DH0, *DZP;
   float *A, *DA, *Bq, *DBq, *Cq, *DCq;
   float *GS, *DGS, *VH, *DVH, *TL, *DTL;
-  float *TYPEV, *AT, *DTT, *DTV, *REP;   // type-shared prefix rows (sched.h TypeShare)
+  float *TYPEV, *AT, *DTT, *DTV, *TG, *TGN, *XPT;   // type-shared prefix rows (sched.h TypeShare)
   Scratch sc[2];
   size_t bytes;
 };
@@ -148,7 +148,9 @@ DecWs dec_ws(const dvae_dims& d, int R, int E, void* base) {
   w.AT = c.f((size_t)32 * d.EHP);
   w.DTT = c.f((size_t)d.EHP * 32);
   w.DTV = c.f((size_t)32 * d.HP);
-  w.REP = c.f(64);
+  w.TG = c.f((size_t)32 * 3 * d.HP);
+  w.TGN = c.f((size_t)32 * d.HP);
+  w.XPT = c.f(32 * 32);
   carve_scratch(c, d, w.sc);
   w.bytes = c.off;
   return w;
@@ -394,8 +396,12 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
 
 // weight gradients of one sweep, reduced over all rows after the sweep.
 // Ggru -> dWhh [3HP][HP]; Xgru / Xgm -> the gradient-only regions of layout.h
+// tg: the k = 0 rows [z1,R) of a prefix sweep are shared by type -- their GRU gradients come as one
+// row per type (k_type_gru_bwd) instead of per-row GH/GHN entries
+struct TypeGrad { const float *TG, *TGN, *XPT; };
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g) {
+                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g,
+                const TypeGrad* tg = nullptr) {
   const int HP = d.HP, PP = pos_cols(d), R = lv.R;
   hipStream_t st = g.st;
   const int RH = R > 0 ? b.RH : 0;
@@ -411,8 +417,18 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
   }
   // dW_ih, db_ih, db_hh = (dgh | dn_pre)^T . (x | 1)
   DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
-  DVAE_TRY(g.tn(b.GH, 3 * HP, b.XP, 32, Xgru, 32, 3 * HP, 32, RH));
-  DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xgru + (size_t)3 * HP * 32, 32, HP, 32, RH));
+  float* Xn = Xgru + (size_t)3 * HP * 32;
+  if (tg && b.prefix) {
+    DVAE_TRY(g.tn(b.GH + (size_t)R * 3 * HP, 3 * HP, b.XP + (size_t)R * 32, 32, Xgru, 32, 3 * HP, 32, RH - R));
+    DVAE_TRY(g.tn(b.GH, 3 * HP, b.XP, 32, Xgru, 32, 3 * HP, 32, z1, 1));
+    DVAE_TRY(g.tn(tg->TG, 3 * HP, tg->XPT, 32, Xgru, 32, 3 * HP, 32, 32, 1));
+    DVAE_TRY(g.tn(b.GHN + (size_t)R * HP, HP, b.XP + (size_t)R * 32, 32, Xn, 32, HP, 32, RH - R));
+    DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xn, 32, HP, 32, z1, 1));
+    DVAE_TRY(g.tn(tg->TGN, HP, tg->XPT, 32, Xn, 32, HP, 32, 32, 1));
+  } else {
+    DVAE_TRY(g.tn(b.GH, 3 * HP, b.XP, 32, Xgru, 32, 3 * HP, 32, RH));
+    DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xn, 32, HP, 32, RH));
+  }
   if (d.mod == 0) {
     const int Rg = lv.nlev > 0 ? lv.ls[lv.nlev - 1] : 0;   // nodes that have a gate/map output
     DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
@@ -508,12 +524,12 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
   DVAE_TRY(g.nn(w.DML, 2 * ZP, P + L.Wml, HP, w.DHVF, HP, B, HP, 2 * ZP));
   if (d_hv) DVAE_TRY(k_add_rows(w.DHVF, HP, d_hv, d.H, B, d.H, st));
 
-  DVAE_CHECK_HIP(hipMemsetAsync(w.f.DH, 0, (size_t)std::max(lf.R, 1) * HP * 4, st));
+  DVAE_TRY(k_zero(w.f.DH, (size_t)std::max(lf.R, 1) * HP * 4, st));
   SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
   if (d.bidir) {
     const Levels lr = levels_of(d, info, 1);
     SweepW wr{gru_at(P + L.gru_b, HP, d.C), P + L.gm_b};
-    DVAE_CHECK_HIP(hipMemsetAsync(w.r.DH, 0, (size_t)std::max(lf.R, 1) * HP * 4, st));
+    DVAE_TRY(k_zero(w.r.DH, (size_t)std::max(lf.R, 1) * HP * 4, st));
     // chain backward; DHVC[t] = dL/d hv_t, DHVC[N] seeded by the heads
     DVAE_CHECK_HIP(hipMemcpyAsync(w.DHVC + (size_t)d.N * B * HP, w.DHVF, (size_t)B * HP * 4,
                                   hipMemcpyDeviceToDevice, st));
@@ -707,8 +723,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     DVAE_TRY(k_build_xp(S, 1, RH, x, d.N, d.C, w.s.XP, sd));
     DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
     DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
-    DVAE_TRY(k_type_gru_bwd(sv.row_type, z1, R, d.C, sw.gru, w.DTV, reinterpret_cast<int*>(w.REP), w.s.GH, w.s.GHN,
-                            HP, sd));
+    DVAE_TRY(k_type_gru_bwd(d.C, sw.gru, w.DTV, w.TG, w.TGN, w.XPT, HP, sd));
     DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R));
     if (!skip0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1, 1));
     DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
@@ -720,7 +735,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
   if (dgs_done) DVAE_CHECK_HIP(hipStreamWaitEvent(st, dgs_done, 0));
-  DVAE_CHECK_HIP(hipMemsetAsync(w.DH0, 0, (size_t)B * HP * 4, st));
+  DVAE_TRY(k_zero(w.DH0, (size_t)B * HP * 4, st));
   DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
 
   // ---- add_edge input gradients, then the level sweep ----
@@ -731,7 +746,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     // k = 0 rows: level 0 (unless it holds node 0 only, which no pair is scored on), and the later
     // levels when they are not shared by type
     const int n0 = skip0 ? z1 : 0, n1 = typed ? z1 : R;
-    if (n0 > 0) DVAE_CHECK_HIP(hipMemsetAsync(w.s.DH, 0, (size_t)n0 * HP * 4, st));
+    if (n0 > 0) DVAE_TRY(k_zero(w.s.DH, (size_t)n0 * HP * 4, st));
     if (n1 > n0)
       DVAE_TRY(g.nn(w.DA + (size_t)n0 * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)n0 * HP, HP, n1 - n0, HP, EHP));
     // edge rows: the scored ones, zeros in the others
@@ -746,7 +761,9 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, Rb, HP, EHP, 1));
   DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, typed));
   DVAE_TRY(ev.edge(st, sd));
-  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs));
+  const TypeGrad tgrad{w.TG, w.TGN, w.XPT};
+  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs,
+                       typed ? &tgrad : nullptr));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
 

@@ -79,11 +79,10 @@ int k_chain_scatter(const SchedDir& Srev, const int* sizes, int B, int N, int t,
                     float* d_t, float* DHb, int HP, hipStream_t st);
 
 // type-shared prefix rows (sched.h TypeShare): TYPEV [32][HP] = GRU(one-hot c, h_in = 0);
-// backward: GH/GHN rows [r0,r1) zeroed, then the first row of each type gets the gate gradients of
-// the per-type sum T[c] = dL/dhv(type)  (rep: 32 ints of scratch)
+// backward: from the per-type sums T[c] = dL/dhv(type), one gate-gradient row per type
+// (TG [32][3HP], TGN [32][HP]) and the (type one-hot | 1) table XPT [32][32] they pair with
 int k_type_states(int C, const GruW& w, float* TYPEV, int HP, hipStream_t st);
-int k_type_gru_bwd(const int* row_type, int r0, int r1, int C, const GruW& w, const float* T, int* rep,
-                   float* GH, float* GHN, int HP, hipStream_t st);
+int k_type_gru_bwd(int C, const GruW& w, const float* T, float* TG, float* TGN, float* XPT, int HP, hipStream_t st);
 
 // decoder glue -----------------------------------------------------------------
 int k_graph_state_fwd(const SchedDir& S, int R, int N, int mod, const float* Hn, const float* h0, float* GS,
@@ -113,6 +112,7 @@ int k_add_dh0(const SchedDir& S, int B, int N, const float* DAGG, float* dh0, in
 // out[r][c] = c < W ? in[r][c] : 0 for c < ncols (in == NULL: zeros)
 int k_pad_rows(const float* in, int rows, int W, float* out, int ld, int ncols, hipStream_t st);
 int k_relu_bwd(float* d, const float* y, size_t n, hipStream_t st);   // d *= (y > 0)
+int k_zero(void* p, size_t bytes, hipStream_t st);   // memset 0, wide kernel for large buffers
 int k_zero_rows(float* X, int ld, int W, const int* rows, int n, hipStream_t st);   // X[rows[i]][0..W) = 0
 int k_unpad_rows(const float* in, int ld, int rows, int W, float* out, hipStream_t st);
 int k_add_rows(float* dst, int ldd, const float* src, int lds_, int rows, int W, hipStream_t st);

@@ -139,53 +139,50 @@ __global__ void type_states_kernel(int C, GruW w, float* __restrict__ TYPEV, int
   }
 }
 
-// rep[c] = first node row in [r0, r1) of type c (rep preset to INT_MAX); block-local minimum
-// first, so the global atomics are 32 per block
-__global__ __launch_bounds__(256) void type_rep_kernel(const int* __restrict__ row_type, int r0, int r1,
-                                                       int* __restrict__ rep) {
-  __shared__ int loc[32];
-  if (threadIdx.x < 32) loc[threadIdx.x] = 0x7fffffff;
-  __syncthreads();
-  for (int r = r0 + blockIdx.x * blockDim.x + threadIdx.x; r < r1; r += gridDim.x * blockDim.x)
-    atomicMin(loc + row_type[r], r);
-  __syncthreads();
-  if (threadIdx.x < 32 && loc[threadIdx.x] != 0x7fffffff) atomicMin(rep + threadIdx.x, loc[threadIdx.x]);
-}
-
 // GRU backward of the type-shared rows.  All rows of a type have the same gates and h_in = 0, so
 // the per-row backward is one linear map per type and only the per-type SUM of dL/dhv matters
-// (T[c]): the type's first row receives the gate gradients of the sum, every other row of
-// [r0,r1) was zeroed by the caller.  Gates are recomputed from the weights (as type_states_kernel).
-__global__ void type_gru_bwd_kernel(int C, GruW w, const int* __restrict__ rep, const float* __restrict__ T,
-                                    float* __restrict__ GH, float* __restrict__ GHN, int HP) {
+// (T[c]).  Output: one gradient row per TYPE -- TG [32][3HP] (r, z, n*r gates), TGN [32][HP]
+// (n pre-activation) -- and XPT [32][32], the (type one-hot | 1) rows the weight-gradient product
+// pairs them with.  Gates are recomputed from the weights (as type_states_kernel).
+__global__ void type_gru_bwd_kernel(int C, GruW w, const float* __restrict__ T, float* __restrict__ TG,
+                                    float* __restrict__ TGN, float* __restrict__ XPT, int HP) {
   const int HP4 = HP >> 2;
-  const long long total = (long long)C * HP4;
+  const long long total = (long long)32 * HP4;
   ITEM_LOOP(total) {
     const int c = (int)(it / HP4), j = (int)(it % HP4) * 4;
-    const int row = rep[c];
-    if (row == 0x7f7f7f7f) continue;   // no row of this type
-    float4 gi[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) gi[g] = fma4(1.f, ld4(w.WihT + (size_t)c * 3 * HP + g * HP + j), ld4(w.bih + g * HP + j));
-    const float4 ghr = ld4(w.bhh + j), ghz = ld4(w.bhh + HP + j), ghn = ld4(w.bhh + 2 * HP + j);
-    const float4 dh = ld4(T + (size_t)c * HP + j);
-    float4 drp, dzp, dnp, dnr;
-#define TB_LANE(f)                                                          \
-    {                                                                       \
-      const float rr = sigm(gi[0].f + ghr.f), zz = sigm(gi[1].f + ghz.f);   \
-      const float nn = tanhf(gi[2].f + rr * ghn.f);                         \
-      dnp.f = dh.f * (1.f - zz) * (1.f - nn * nn);                          \
-      dzp.f = dh.f * (0.f - nn) * zz * (1.f - zz);                          \
-      drp.f = dnp.f * ghn.f * rr * (1.f - rr);                              \
-      dnr.f = dnp.f * rr;                                                   \
+    if (j < 32) {
+      const int q = j >> 2;   // columns 4q .. 4q+3 of XPT row c
+      float4 o;
+      o.x = (c < C && (4 * q == c || 4 * q == C)) ? 1.f : 0.f;
+      o.y = (c < C && (4 * q + 1 == c || 4 * q + 1 == C)) ? 1.f : 0.f;
+      o.z = (c < C && (4 * q + 2 == c || 4 * q + 2 == C)) ? 1.f : 0.f;
+      o.w = (c < C && (4 * q + 3 == c || 4 * q + 3 == C)) ? 1.f : 0.f;
+      st4(XPT + c * 32 + j, o);
     }
-    TB_LANE(x) TB_LANE(y) TB_LANE(z) TB_LANE(w)
+    float4 drp = zero4(), dzp = zero4(), dnp = zero4(), dnr = zero4();
+    if (c < C) {
+      float4 gi[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gi[g] = fma4(1.f, ld4(w.WihT + (size_t)c * 3 * HP + g * HP + j), ld4(w.bih + g * HP + j));
+      const float4 ghr = ld4(w.bhh + j), ghz = ld4(w.bhh + HP + j), ghn = ld4(w.bhh + 2 * HP + j);
+      const float4 dh = ld4(T + (size_t)c * HP + j);
+#define TB_LANE(f)                                                          \
+      {                                                                       \
+        const float rr = sigm(gi[0].f + ghr.f), zz = sigm(gi[1].f + ghz.f);   \
+        const float nn = tanhf(gi[2].f + rr * ghn.f);                         \
+        dnp.f = dh.f * (1.f - zz) * (1.f - nn * nn);                          \
+        dzp.f = dh.f * (0.f - nn) * zz * (1.f - zz);                          \
+        drp.f = dnp.f * ghn.f * rr * (1.f - rr);                              \
+        dnr.f = dnp.f * rr;                                                   \
+      }
+      TB_LANE(x) TB_LANE(y) TB_LANE(z) TB_LANE(w)
 #undef TB_LANE
-    float* gh = GH + (size_t)row * 3 * HP;
+    }
+    float* gh = TG + (size_t)c * 3 * HP;
     st4(gh + j, drp);
     st4(gh + HP + j, dzp);
     st4(gh + 2 * HP + j, dnr);
-    st4(GHN + (size_t)row * HP + j, dnp);
+    st4(TGN + (size_t)c * HP + j, dnp);
   }
 }
 
@@ -574,6 +571,11 @@ __global__ void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__
     if (!(y[i] > 0.f)) d[i] = 0.f;
 }
 
+__global__ void zero_kernel(float4* __restrict__ p, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // X[rows[i]][0..W) = 0 (W a multiple of 4)
 __global__ void zero_rows_kernel(float* __restrict__ X, int ld, int W, const int* __restrict__ rows, int n) {
   const int wq = W >> 2;
@@ -953,15 +955,9 @@ int k_type_states(int C, const GruW& w, float* TYPEV, int HP, hipStream_t st) {
   return DVAE_OK;
 }
 
-int k_type_gru_bwd(const int* row_type, int r0, int r1, int C, const GruW& w, const float* T, int* rep,
-                   float* GH, float* GHN, int HP, hipStream_t st) {
-  if (r1 <= r0) return DVAE_OK;
-  DVAE_CHECK_HIP(hipMemsetAsync(rep, 0x7f, 32 * sizeof(int), st));
-  DVAE_CHECK_HIP(hipMemsetAsync(GH + (size_t)r0 * 3 * HP, 0, (size_t)(r1 - r0) * 3 * HP * sizeof(float), st));
-  DVAE_CHECK_HIP(hipMemsetAsync(GHN + (size_t)r0 * HP, 0, (size_t)(r1 - r0) * HP * sizeof(float), st));
-  hipLaunchKernelGGL(type_rep_kernel, grid_for(r1 - r0, 256), dim3(256), 0, st, row_type, r0, r1, rep);
-  hipLaunchKernelGGL(type_gru_bwd_kernel, grid_for((long long)C * (HP / 4)), dim3(256), 0, st, C, w, rep, T, GH,
-                     GHN, HP);
+int k_type_gru_bwd(int C, const GruW& w, const float* T, float* TG, float* TGN, float* XPT, int HP, hipStream_t st) {
+  hipLaunchKernelGGL(type_gru_bwd_kernel, grid_for((long long)32 * (HP / 4)), dim3(256), 0, st, C, w, T, TG, TGN,
+                     XPT, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
@@ -1209,6 +1205,20 @@ int k_pad_rows(const float* in, int rows, int W, float* out, int ld, int ncols, 
 int k_relu_bwd(float* d, const float* y, size_t n, hipStream_t st) {
   if (n == 0) return DVAE_OK;
   hipLaunchKernelGGL(relu_bwd_kernel, grid_for((long long)n), dim3(256), 0, st, d, y, n);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+// large buffers: the runtime's fill kernel runs 256 workgroups (about 0.6 TB/s measured here)
+int k_zero(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return DVAE_OK;
+  if (bytes < ((size_t)1 << 20) || (((uintptr_t)p | bytes) & 15)) {
+    DVAE_CHECK_HIP(hipMemsetAsync(p, 0, bytes, st));
+    return DVAE_OK;
+  }
+  const size_t n4 = bytes / 16;
+  const int grid = (int)std::min<size_t>((n4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4*>(p), n4);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
