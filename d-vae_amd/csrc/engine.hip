@@ -353,7 +353,8 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
 
 // reverse-level sweep: DH holds dL/dHV on entry, dL/dAGG on exit
 int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
-              bool seeded, const G& g, bool k0_shared = false) {
+              bool seeded, const G& g, bool k0_shared = false,
+              const std::function<int(int)>& after_level = nullptr) {
   const int HP = d.HP, R = lv.R;
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
@@ -388,57 +389,106 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
       DVAE_TRY(dagg_gemm(p0, p1));
     }
+    if (after_level) DVAE_TRY(after_level(L));   // levels >= L are final from here on
   }
   // k = 0 rows of the later levels feed nothing backwards except the weight gradients
   if (b.prefix && !k0_shared) DVAE_TRY(k_gru_bwd(S, z1, R, b, HP, st));
   return DVAE_OK;
 }
 
-// weight gradients of one sweep, reduced over all rows after the sweep.
+// weight gradients of one sweep, reduced over the rows of levels [La, Lb).
 // Ggru -> dWhh [3HP][HP]; Xgru / Xgm -> the gradient-only regions of layout.h
-// tg: the k = 0 rows [z1,R) of a prefix sweep are shared by type -- their GRU gradients come as one
-// row per type (k_type_gru_bwd) instead of per-row GH/GHN entries
+// first: this call sets the outputs (and builds the one-hot tables), later calls accumulate.
+// The chunk with La = 0 also takes what belongs to no level: the k = 0 rows of a prefix sweep.
+// tg: those rows, [z1,R), are shared by type -- their GRU gradients come as one row per type
+// (k_type_gru_bwd) instead of per-row GH/GHN entries
 struct TypeGrad { const float *TG, *TGN, *XPT; };
+struct WgradOut { float *Ggru, *Ggm, *Xgru, *Xgm; };
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                float* Ggru, float* Ggm, float* Xgru, float* Xgm, bool seeded, const G& g,
-                const TypeGrad* tg = nullptr) {
+                const WgradOut& o, bool seeded, const G& g, const TypeGrad* tg, int La, int Lb, bool first) {
   const int HP = d.HP, PP = pos_cols(d), R = lv.R;
   hipStream_t st = g.st;
   const int RH = R > 0 ? b.RH : 0;
   const int z1 = (R > 0 && lv.nlev > 0) ? lv.ls[1] : 0;
-  // dWhh = dgh^T . h_in over the rows whose h_in is not identically zero
-  if (!b.prefix) {
-    const int skip = d.mod == 0 ? z1 : 0;      // level 0 of a node sweep has h_in = 0
-    DVAE_TRY(g.tn(b.GH + (size_t)skip * 3 * HP, 3 * HP, b.AGG + (size_t)skip * HP, HP, Ggru, HP, 3 * HP, HP,
-                  R - skip));
-  } else {
-    DVAE_TRY(g.tn(b.GH + (size_t)R * 3 * HP, 3 * HP, b.AGG + (size_t)R * HP, HP, Ggru, HP, 3 * HP, HP, RH - R));
-    if (seeded && z1 > 0) DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, Ggru, HP, 3 * HP, HP, z1, 1));
+  const int Rg = (d.mod == 0 && lv.nlev > 0) ? lv.ls[lv.nlev - 1] : 0;   // nodes that have a gate/map output
+  const int acc = first ? 0 : 1;
+  const bool low = La == 0;
+  if (R <= 0) { La = 0; Lb = 0; }
+  if (first) {
+    DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
+    if (d.mod == 0) DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
+    else DVAE_TRY(k_build_xp(S, 0, R, x, d.N, d.C, b.PX, st));
   }
-  // dW_ih, db_ih, db_hh = (dgh | dn_pre)^T . (x | 1)
-  DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
-  float* Xn = Xgru + (size_t)3 * HP * 32;
-  if (tg && b.prefix) {
-    DVAE_TRY(g.tn(b.GH + (size_t)R * 3 * HP, 3 * HP, b.XP + (size_t)R * 32, 32, Xgru, 32, 3 * HP, 32, RH - R));
-    DVAE_TRY(g.tn(b.GH, 3 * HP, b.XP, 32, Xgru, 32, 3 * HP, 32, z1, 1));
-    DVAE_TRY(g.tn(tg->TG, 3 * HP, tg->XPT, 32, Xgru, 32, 3 * HP, 32, 32, 1));
-    DVAE_TRY(g.tn(b.GHN + (size_t)R * HP, HP, b.XP + (size_t)R * 32, 32, Xn, 32, HP, 32, RH - R));
-    DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xn, 32, HP, 32, z1, 1));
-    DVAE_TRY(g.tn(tg->TGN, HP, tg->XPT, 32, Xn, 32, HP, 32, 32, 1));
+  float* Xn = o.Xgru + (size_t)3 * HP * 32;
+  auto gru_rows = [&](int r0, int r1, int a) -> int {   // dW_ih, db_ih, db_hh = (dgh | dn_pre)^T . (x | 1)
+    if (r1 <= r0 && a) return DVAE_OK;
+    DVAE_TRY(g.tn(b.GH + (size_t)r0 * 3 * HP, 3 * HP, b.XP + (size_t)r0 * 32, 32, o.Xgru, 32, 3 * HP, 32, r1 - r0, a));
+    return g.tn(b.GHN + (size_t)r0 * HP, HP, b.XP + (size_t)r0 * 32, 32, Xn, 32, HP, 32, r1 - r0, a);
+  };
+  const int n0 = R > 0 ? lv.ls[La] : 0, n1 = R > 0 ? lv.ls[Lb] : 0;   // node rows of the chunk
+  if (!b.prefix) {
+    // dWhh = dgh^T . h_in over the rows whose h_in is not identically zero (level 0 of a node sweep has h_in = 0)
+    const int r0 = d.mod == 0 ? std::max(n0, z1) : n0;
+    DVAE_TRY(g.tn(b.GH + (size_t)r0 * 3 * HP, 3 * HP, b.AGG + (size_t)r0 * HP, HP, o.Ggru, HP, 3 * HP, HP, n1 - r0, acc));
+    DVAE_TRY(gru_rows(n0, n1, acc));
   } else {
-    DVAE_TRY(g.tn(b.GH, 3 * HP, b.XP, 32, Xgru, 32, 3 * HP, 32, RH));
-    DVAE_TRY(g.tn(b.GHN, HP, b.XP, 32, Xn, 32, HP, 32, RH));
+    const int e0 = R > 0 ? R + lv.es[La] : 0, e1 = R > 0 ? R + lv.es[Lb] : 0;   // edge rows of the chunk
+    DVAE_TRY(g.tn(b.GH + (size_t)e0 * 3 * HP, 3 * HP, b.AGG + (size_t)e0 * HP, HP, o.Ggru, HP, 3 * HP, HP, e1 - e0, acc));
+    DVAE_TRY(gru_rows(e0, e1, acc));
+    if (low) {
+      if (seeded && z1 > 0) DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, o.Ggru, HP, 3 * HP, HP, z1, 1));
+      if (tg) {
+        DVAE_TRY(gru_rows(0, z1, 1));
+        DVAE_TRY(g.tn(tg->TG, 3 * HP, tg->XPT, 32, o.Xgru, 32, 3 * HP, 32, 32, 1));
+        DVAE_TRY(g.tn(tg->TGN, HP, tg->XPT, 32, Xn, 32, HP, 32, 32, 1));
+      } else {
+        DVAE_TRY(gru_rows(0, R, 1));
+      }
+    }
   }
   if (d.mod == 0) {
-    const int Rg = lv.nlev > 0 ? lv.ls[lv.nlev - 1] : 0;   // nodes that have a gate/map output
-    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.Hn, HP, Ggm, HP, 2 * HP, HP, Rg));
-    DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
-    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, PP, Xgm, PP, 2 * HP, PP, Rg));
+    const int r1 = std::min(n1, Rg);
+    DVAE_TRY(g.tn(b.GMP + (size_t)n0 * 2 * HP, 2 * HP, b.Hn + (size_t)n0 * HP, HP, o.Ggm, HP, 2 * HP, HP, r1 - n0, acc));
+    DVAE_TRY(g.tn(b.GMP + (size_t)n0 * 2 * HP, 2 * HP, b.PX + (size_t)n0 * PP, PP, o.Xgm, PP, 2 * HP, PP, r1 - n0, acc));
   } else {
-    DVAE_TRY(k_build_xp(S, 0, R, x, d.N, d.C, b.PX, st));
-    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, 32, Xgm, 32, 2 * HP, 32, R));
+    DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, 32, o.Xgm, 32, 2 * HP, 32, R, acc));
   }
   return DVAE_OK;
+}
+
+// The level from which the weight-gradient products of a sweep are issued early: once the
+// backward sweep has passed level L0, the rows of levels >= L0 are final and their products run
+// on the side stream beside the rest of the sweep (which alone leaves the matrix cores idle
+// between its per-level launches); the lower levels follow after the sweep.  One early chunk
+// only: per-level products were measured slower (small launches).  0 = no early chunk.
+// DVAE_WGRAD_SPLIT=<fraction of rows in the early chunk, 0 = off> (default 0.35).
+int wgrad_split_level(const dvae_dims& d, const Levels& lv, bool prefix, bool two_streams) {
+  static const double frac = getenv("DVAE_WGRAD_SPLIT") ? atof(getenv("DVAE_WGRAD_SPLIT")) : 0.35;
+  if (!two_streams || frac <= 0.0 || d.mod != 0 || lv.nlev < 3) return 0;
+  const int* cum = prefix ? lv.es : lv.ls;
+  const int T = cum[lv.nlev];
+  if (T < 16384) return 0;   // small batches: the split only adds launches
+  int L0 = 0;
+  for (int L = 1; L < lv.nlev; ++L)
+    if ((double)(T - cum[L]) >= frac * T) L0 = L;
+  return L0;
+}
+
+// backward sweep on the chain + its weight-gradient products on the side stream
+int sweep_bwd_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
+                    const float* x, const WgradOut& o, bool seeded, const G& g, const G& gs, Events& ev,
+                    bool k0_shared = false, const TypeGrad* tg = nullptr) {
+  const int L0 = wgrad_split_level(d, lv, b.prefix, g.st != gs.st);
+  bool early = false;
+  std::function<int(int)> after = [&](int L) -> int {
+    if (L != L0 || L0 <= 0) return DVAE_OK;
+    DVAE_TRY(ev.edge(g.st, gs.st));
+    early = true;
+    return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, L0, lv.nlev, true);
+  };
+  DVAE_TRY(sweep_bwd(d, S, lv, b, w, seeded, g, k0_shared, after));
+  DVAE_TRY(ev.edge(g.st, gs.st));
+  return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, 0, early ? L0 : lv.nlev, !early);
 }
 
 }  // namespace
@@ -548,17 +598,13 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     DVAE_TRY(ev.edge(st, sd));
     DVAE_TRY(gs.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
     DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, ssc.part, ssc.part_floats, sd));
-    DVAE_TRY(sweep_bwd(d, sv.dir[1], lr, w.r, wr, false, g));
-    DVAE_TRY(ev.edge(st, sd));
-    DVAE_TRY(sweep_wgrad(d, sv.dir[1], lr, w.r, x, Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b,
-                         false, gs));
+    DVAE_TRY(sweep_bwd_wgrad(d, sv.dir[1], lr, w.r, wr, x,
+                             WgradOut{Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b}, false, g, gs, ev));
   } else {
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
-  DVAE_TRY(sweep_bwd(d, sv.dir[0], lf, w.f, wf, false, g));
-  DVAE_TRY(ev.edge(st, sd));
-  DVAE_TRY(sweep_wgrad(d, sv.dir[0], lf, w.f, x, Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f, false,
-                       gs));
+  DVAE_TRY(sweep_bwd_wgrad(d, sv.dir[0], lf, w.f, wf, x,
+                           WgradOut{Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f}, false, g, gs, ev));
   return DVAE_OK;
 }
 
@@ -759,11 +805,9 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     }
   }
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, Rb, HP, EHP, 1));
-  DVAE_TRY(sweep_bwd(d, S, lv, w.s, sw, true, g, typed));
-  DVAE_TRY(ev.edge(st, sd));
   const TypeGrad tgrad{w.TG, w.TGN, w.XPT};
-  DVAE_TRY(sweep_wgrad(d, S, lv, w.s, x, Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm, true, gs,
-                       typed ? &tgrad : nullptr));
+  DVAE_TRY(sweep_bwd_wgrad(d, S, lv, w.s, sw, x, WgradOut{Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm}, true,
+                           g, gs, ev, typed, typed ? &tgrad : nullptr));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
 
