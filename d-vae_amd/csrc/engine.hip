@@ -780,9 +780,6 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, Rb));
   DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
-  if (dgs_done) DVAE_CHECK_HIP(hipStreamWaitEvent(st, dgs_done, 0));
-  DVAE_TRY(k_zero(w.DH0, (size_t)B * HP * 4, st));
-  DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
 
   // ---- add_edge input gradients, then the level sweep ----
   // (measured and dropped: producing dA.W1a / dBq.W1b level by level just ahead of the sweep and
@@ -804,6 +801,11 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
       DVAE_TRY(g.nn(w.DA + (size_t)R * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)R * HP, HP, RH - R, HP, EHP));
     }
   }
+  // the add_vertex input gradient (side stream) is needed from here on only: the product above
+  // runs while the side stream still computes it
+  if (dgs_done) DVAE_CHECK_HIP(hipStreamWaitEvent(st, dgs_done, 0));
+  DVAE_TRY(k_zero(w.DH0, (size_t)B * HP * 4, st));
+  DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, Rb, HP, EHP, 1));
   const TypeGrad tgrad{w.TG, w.TGN, w.XPT};
   DVAE_TRY(sweep_bwd_wgrad(d, S, lv, w.s, sw, x, WgradOut{Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm}, true,
