@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 H, Z, N, C = 501, 56, 8, 8
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PROF_EVERY = 4                   # timed steps between two steps whose GEMM launches carry HIP events
 
 
 def algorithmic_flops_per_dag(n, e):
@@ -148,19 +149,25 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    prof = not args.no_profile and world == 1      # per-launch HIP events: roofline figures are an N=1 report
-    if prof:
-        lib.dvae_gemm_profile(1)
+    # per-launch HIP events (roofline figures, an N=1 report) on every PROF_EVERY-th timed step: two
+    # event records around each of ~110 launches cost 0.44 ms on a 12.4 ms step when every step has them
+    prof = not args.no_profile and world == 1
+    prof_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        sample = prof and i % PROF_EVERY == 0
+        if sample:
+            lib.dvae_gemm_profile(2 if prof_steps else 1)
+            prof_steps += 1
         out4 = step(args.warmup + i)
+        if sample:
+            lib.dvae_gemm_profile(0)
     barrier()
     dt = time.perf_counter() - t0
     gemm = None
     if prof:
         buf = (ctypes.c_double * 12)()
         _lib.check(lib.dvae_gemm_profile_read(ctypes.cast(buf, ctypes.c_void_p)))
-        lib.dvae_gemm_profile(0)
         gemm = list(buf)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -187,19 +194,20 @@ def main():
             launches = gemm[0] + gemm[3] + gemm[9]
             kms = gemm[1] + gemm[4] + gemm[10]
             executed = gemm[2] + gemm[5] + gemm[11]
-            algo = algorithmic_flops_per_dag(N, mean_e) * B_local * args.steps
+            algo = algorithmic_flops_per_dag(N, mean_e) * B_local * prof_steps
             busy = gemm[6] if gemm[6] > 0 else kms     # wall time with >= 1 GEMM launch running
             ach = algo / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
             res["roofline"] = {
                 "bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                 "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "launches_per_step": launches / args.steps, "kernel_busy_ms_per_step": busy / args.steps,
-                "sum_launch_ms_per_step": kms / args.steps,
+                "launches_per_step": launches / prof_steps, "kernel_busy_ms_per_step": busy / prof_steps,
+                "sum_launch_ms_per_step": kms / prof_steps, "timed_steps_with_events": prof_steps,
                 "avg_launch_us": kms / max(launches, 1) * 1e3,
                 "executed_tflops": executed / (busy * 1e-3) / 1e12 if busy > 0 else 0.0,
-                "note": "launches run on two streams and overlap: achieved = algorithmic FLOPs / wall time "
-                        "with at least one launch of the kernel running; avg_launch_us is the plain per-launch mean",
+                "note": "HIP events around every launch of the kernel on every %d-th timed step; launches run on "
+                        "two streams and overlap: achieved = algorithmic FLOPs / wall time with at least one "
+                        "launch of the kernel running; avg_launch_us is the plain per-launch mean" % PROF_EVERY,
                 "algorithmic_gflop_per_dag": algorithmic_flops_per_dag(N, mean_e) / 1e9,
             }
         if world == 1 and not args.no_cpu_baseline:

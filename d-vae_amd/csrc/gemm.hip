@@ -494,9 +494,10 @@ extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float*
 }
 
 // variant: 0 NT, 1 NN, 3 TN.  out3[v] = {launches, milliseconds, executed flops}
+// enable: 1 start a new log, 2 resume the current one, 0 pause (the log is kept until it is read)
 extern "C" int dvae_gemm_profile(int enable) {
   g_prof.on = enable != 0;
-  g_prof.used = 0;
+  if (enable == 1) g_prof.used = 0;
   return DVAE_OK;
 }
 

@@ -68,7 +68,8 @@ int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb
                   float* C, int ldc, int M, int N, int K, const float* bias, int relu,
                   int accumulate, float* ws, size_t ws_bytes, void* stream);
 
-/* Instrumentation for bench.py (no counterpart in the reference): while enabled,
+/* Instrumentation for bench.py (no counterpart in the reference): while enabled
+ * (dvae_gemm_profile: 1 = start a new log, 2 = resume the current log, 0 = pause),
  * every GEMM launch is bracketed by HIP events on its own stream.
  * dvae_gemm_profile_read waits for them and fills out12 = 4 x {launches, ms,
  * executed flops} indexed by layout (0 NT, 1 NN, 3 TN), then clears the log;
