@@ -61,6 +61,8 @@ struct GemmDesc {
                        //    that chain launches arriving later still find free slots on every CU
   const int* row_map;  // optional (m-major A only): row m of the product reads A row row_map[m] and
                        // writes C row row_map[m] -- a product over a scattered subset of rows
+  const int* k_map;    // optional (both operands k-major): reduction index k reads memory row k_map[k]
+                       // of A and of B -- a weight gradient summed over a scattered subset of rows
 };
 // C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);

@@ -192,18 +192,19 @@ struct G {
   // Y[M][N] (+)= X[M][K] W[N][K]^T + bias
   int nt(const float* X, int ldx, const float* W, int ldw, float* Y, int ldy, int M, int N, int K,
          const float* bias = nullptr, int relu = 0, int acc = 0, const int* rows = nullptr) const {
-    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio, bulk, rows};
+    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio, bulk, rows, nullptr};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dX[M][N] (+)= dY[M][K] W[K][N]
   int nn(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K,
          int acc = 0, const int* rows = nullptr) const {
-    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio, bulk, rows};
+    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio, bulk, rows, nullptr};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dW[M][N] (+)= dY[K][M]^T X[K][N]   (K = rows)
+  // krows: the K summed rows are rows krows[0..K) of dY and X
   int tn(const float* dY, int ldy, const float* X, int ldx, float* dW, int ldw, int M, int N, int K,
-         int acc = 0) const {
+         int acc = 0, const int* krows = nullptr) const {
     if (K <= 0) {
       if (acc) return DVAE_OK;
       if (hipMemset2DAsync(dW, (size_t)ldw * 4, 0, (size_t)N * 4, M, st) != hipSuccess) {
@@ -212,7 +213,7 @@ struct G {
       }
       return DVAE_OK;
     }
-    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc, prio, bulk, nullptr};
+    GemmDesc d{dY, ldy, 1, X, ldx, 1, dW, ldw, M, N, K, nullptr, 0, acc, prio, bulk, nullptr, krows};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
 };
@@ -752,6 +753,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const int z1 = lv.nlev > 0 ? lv.ls[1] : R;
   const TypeShare ts{typed ? w.AT : nullptr, z1};
   const bool scored = scored_rows_only(), skip0 = skip_level0(info);
+  const int U = (scored && lv.as[d.N] <= lv.E) ? lv.as[d.N] : -1;   // scored edge rows (sv.a_rows), -1: all rows
   if (pair_bwd_fused_ok(d.N, EHP)) {
     DVAE_TRY(k_pair_bwd_fused(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.w2, msc.part,
                               msc.part_floats, EHP, st));
@@ -770,7 +772,8 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
     DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
     DVAE_TRY(k_type_gru_bwd(d.C, sw.gru, w.DTV, w.TG, w.TGN, w.XPT, HP, sd));
-    DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R));
+    if (U >= 0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, U, 0, sv.a_rows));
+    else DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R));
     if (!skip0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1, 1));
     DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
   } else {
@@ -793,8 +796,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     if (n1 > n0)
       DVAE_TRY(g.nn(w.DA + (size_t)n0 * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)n0 * HP, HP, n1 - n0, HP, EHP));
     // edge rows: the scored ones, zeros in the others
-    const int U = scored ? lv.as[d.N] : -1;
-    if (U >= 0 && U <= lv.E) {
+    if (U >= 0) {
       DVAE_TRY(k_zero_rows(w.s.DH, HP, HP, sv.a_skip, lv.E - U, st));
       DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, U, HP, EHP, 0, sv.a_rows));
     } else {

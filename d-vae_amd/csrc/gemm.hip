@@ -59,6 +59,36 @@ struct Tile {
     }
   }
 
+  // k-major operand whose reduction rows are gathered through `kmap` (reduction index k reads
+  // memory row kmap[k]): kq holds the memory rows of the NEXT tile this thread loads, fetched one
+  // tile ahead so that the dependent index load is off the critical path
+  int kq[NV];
+  __device__ __forceinline__ void kq_fetch(const int* __restrict__ kmap, int k0, int kend, int tid) {
+    constexpr int RQ = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) kq[i] = kmap[min(k0 + tid / RQ + i * (256 / RQ), kend - 1)];
+  }
+  // full tile, no predicates (as load<false>); rows of the reduction come from kq
+  __device__ __forceinline__ void load_gathered(const float* __restrict__ P, int ld, int r0, int rows, int tid) {
+    constexpr int RQ = ROWS / 4;
+    const int r = min(r0 + (tid % RQ) * 4, rows - 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(P + (size_t)kq[i] * ld + r);
+  }
+  // last (possibly partial) tiles: predicated, index loaded in place
+  __device__ __forceinline__ void load_gathered_checked(const float* __restrict__ P, int ld, int r0, int rows, int k0,
+                                                        int kend, const int* __restrict__ kmap, int tid) {
+    constexpr int RQ = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int k = k0 + idx / RQ, r = r0 + (idx % RQ) * 4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < kend && r < rows) val = *reinterpret_cast<const float4*>(P + (size_t)kmap[k] * ld + r);
+      v[i] = val;
+    }
+  }
+
   // rows: extent of the non-reduction dim; kend: end of this block's k range.
   // CHECK = false: the caller guarantees that the k range [k0, k0+BK) lies inside the
   // reduction; row indices beyond `rows` are clamped to the last valid row(s), whose
@@ -137,6 +167,7 @@ struct GemmParams {
   int dbg;                // lab only
   int prio;               // wave priority (s_setprio): the per-level chain outranks the bulk side-stream products
   const int* row_map;     // optional: row m of the product reads A row row_map[m] and writes C row row_map[m]
+  const int* k_map;       // optional (both operands k-major, KG kernels): reduction index k reads row k_map[k]
 };
 
 // bijective XCD-aware remap: blocks that share blockIdx%8 (one XCD under
@@ -149,8 +180,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + j;
 }
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2, bool KG = false>
 __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
+  static_assert(!KG || (AKM == 1 && BKM == 1), "a gathered reduction needs two k-major operands");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
   using TA = Tile<AKM, BM, BK>;
@@ -186,8 +218,15 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   TB tb;
   ta.rows_init(p.lda, m0, p.M, AKM == 0 ? p.row_map : nullptr, tid);
   tb.rows_init(p.ldb, n0, p.N, nullptr, tid);
-  ta.template load<true>(p.A, p.lda, m0, p.M, kb, ke, tid);
-  tb.template load<true>(p.B, p.ldb, n0, p.N, kb, ke, tid);
+  if (KG) {
+    ta.load_gathered_checked(p.A, p.lda, m0, p.M, kb, ke, p.k_map, tid);
+    tb.load_gathered_checked(p.B, p.ldb, n0, p.N, kb, ke, p.k_map, tid);
+    ta.kq_fetch(p.k_map, kb + BK, ke, tid);
+    tb.kq_fetch(p.k_map, kb + BK, ke, tid);
+  } else {
+    ta.template load<true>(p.A, p.lda, m0, p.M, kb, ke, tid);
+    tb.template load<true>(p.B, p.ldb, n0, p.N, kb, ke, tid);
+  }
   ta.store(lds, tid);
   tb.store(lds + TA::LDS_FLOATS, tid);
   __syncthreads();
@@ -235,7 +274,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   // hot loop: the next k-tile is a full one, loaded without predicates or branches (a loop
   // body with both load forms makes the compiler wait for the loads where the forms merge)
   for (; k0 + 2 * BK <= ke; k0 += BK) {
-    if (!(p.dbg & 2)) {
+    if (KG) {
+      ta.load_gathered(p.A, p.lda, m0, p.M, tid);
+      tb.load_gathered(p.B, p.ldb, n0, p.N, tid);
+      ta.kq_fetch(p.k_map, k0 + 2 * BK, ke, tid);   // rows of the tile after this one
+      tb.kq_fetch(p.k_map, k0 + 2 * BK, ke, tid);
+    } else if (!(p.dbg & 2)) {
       ta.template load<false>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
       tb.template load<false>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
     }
@@ -246,8 +290,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   for (; k0 < ke; k0 += BK) {
     const bool more = (k0 + BK) < ke;
     if (more) {
-      ta.template load<true>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
-      tb.template load<true>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
+      if (KG) {
+        ta.load_gathered_checked(p.A, p.lda, m0, p.M, k0 + BK, ke, p.k_map, tid);
+        tb.load_gathered_checked(p.B, p.ldb, n0, p.N, k0 + BK, ke, p.k_map, tid);
+      } else {
+        ta.template load<true>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
+        tb.template load<true>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
+      }
     }
     compute();
     if (more) refill();
@@ -369,7 +418,7 @@ void gemm_prof_end(void* h, hipStream_t st) { prof_end(static_cast<GemmProf*>(h)
 
 namespace {
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1, int MINB = 2>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1, int MINB = 2, bool KG = false>
 int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   GemmParams p;
   p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias;
@@ -379,6 +428,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   p.prio = g_force_prio >= 0 ? g_force_prio : d.prio;
   p.dbg = g_dbg;
   p.row_map = d.row_map;
+  p.k_map = d.k_map;
   const int tiles_m = cdiv(d.M, BM);
   p.tiles_n = cdiv(d.N, BN);
   p.nblk = tiles_m * p.tiles_n;
@@ -410,8 +460,8 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     p.c_split = 0;
   }
   GemmProf* pr = prof_begin(AKM * 2 + BKM, 2.0 * d.M * d.N * d.K, stream);
-  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST, MINB>), dim3(p.nblk, splits), dim3(256), 0,
-                     stream, p);
+  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST, MINB, KG>), dim3(p.nblk, splits), dim3(256),
+                     0, stream, p);
   prof_end(pr, stream);
   DVAE_LAUNCH_CHECK();
   if (splits > 1) {
@@ -438,6 +488,12 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   if (d.M <= 0 || d.N <= 0) return DVAE_OK;
   DVAE_REQUIRE(d.K > 0, "gemm: K must be positive");
   DVAE_REQUIRE(!d.row_map || !d.a_kmajor, "gemm: a row map needs an m-major A");
+  if (d.k_map) {
+    // gathered reduction rows: the weight-gradient shape only (TN, 128x128 tiles, split K)
+    DVAE_REQUIRE(d.a_kmajor && d.b_kmajor && (d.M & 3) == 0 && (d.N & 3) == 0 && d.N > 32,
+                 "gemm: a reduction map needs two k-major operands and N > 32");
+    return launch<1, 1, 128, 128, 2, 2, 16, 1, 2, true>(d, ws, ws_bytes, stream);
+  }
   DVAE_REQUIRE(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0, "gemm: operands must be 16-byte aligned");
   DVAE_REQUIRE((d.lda & 3) == 0 && (d.ldb & 3) == 0, "gemm: leading dimensions must be multiples of 4");
   // the contiguous extent of every operand is loaded as float4
@@ -489,7 +545,7 @@ extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float*
   d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
   d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
   d.bias = bias; d.relu = relu; d.accumulate = accumulate;
-  d.prio = 0; d.bulk = 0; d.row_map = nullptr;
+  d.prio = 0; d.bulk = 0; d.row_map = nullptr; d.k_map = nullptr;
   return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
 }
 
