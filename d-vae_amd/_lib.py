@@ -52,6 +52,8 @@ SIGNATURES = {
     "dvae_dims_init": (c_int, [_P(DvaeDims)]),
     "dvae_gemm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                               c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "dvae_gemm_f32_mapped": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dvae_gemm_force_tile": (c_int, [c_int]),
     "dvae_gemm_tune": (c_int, [c_int, c_int]),
     "dvae_gemm_variant": (c_int, [c_int]),

@@ -549,6 +549,20 @@ extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float*
   return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" int dvae_gemm_f32_mapped(const float* A, int lda, int a_kmajor, const float* B, int ldb,
+                                    int b_kmajor, float* C, int ldc, int M, int N, int K, int accumulate,
+                                    const int* row_map, const int* k_map, float* ws, size_t ws_bytes,
+                                    void* stream) {
+  DVAE_REQUIRE(!(row_map && k_map), "gemm: one map at a time");
+  GemmDesc d;
+  d.A = A; d.lda = lda; d.a_kmajor = a_kmajor;
+  d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
+  d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
+  d.bias = nullptr; d.relu = 0; d.accumulate = accumulate;
+  d.prio = 0; d.bulk = 0; d.row_map = row_map; d.k_map = k_map;
+  return gemm_f32(d, ws, ws_bytes, (hipStream_t)stream);
+}
+
 // variant: 0 NT, 1 NN, 3 TN.  out3[v] = {launches, milliseconds, executed flops}
 // enable: 1 start a new log, 2 resume the current one, 0 pause (the log is kept until it is read)
 extern "C" int dvae_gemm_profile(int enable) {

@@ -68,6 +68,16 @@ int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb
                   float* C, int ldc, int M, int N, int K, const float* bias, int relu,
                   int accumulate, float* ws, size_t ws_bytes, void* stream);
 
+/* The same product over a scattered subset of rows (device int32 index arrays), as the
+ * decoder uses it for add_edge's first layer, which dvae_model.py:210-220 evaluates on the
+ * prefix states some pair is scored on only:
+ *   row_map (A m-major):   row m of the product reads A row row_map[m], writes C row row_map[m]
+ *   k_map (A, B k-major):  reduction index k reads row k_map[k] of A and of B
+ * (at most one of the two; no bias / relu). */
+int dvae_gemm_f32_mapped(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor,
+                         float* C, int ldc, int M, int N, int K, int accumulate, const int* row_map,
+                         const int* k_map, float* ws, size_t ws_bytes, void* stream);
+
 /* Instrumentation for bench.py (no counterpart in the reference): while enabled
  * (dvae_gemm_profile: 1 = start a new log, 2 = resume the current log, 0 = pause),
  * every GEMM launch is bracketed by HIP events on its own stream.

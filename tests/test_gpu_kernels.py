@@ -36,6 +36,57 @@ def test_gemm_nt(cuda, M, N, K):
     assert torch.allclose(out.double(), ref.clamp(min=0), rtol=1e-5, atol=1e-4 * K ** 0.5)
 
 
+def _gemm_mapped(lib, A, a_km, Bm, b_km, C, M, N, K, acc=0, row_map=None, k_map=None):
+    from dvae_amd import engine as E
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=A.device)
+    E.check(lib.dvae_gemm_f32_mapped(E._ptr(A), A.stride(0), a_km, E._ptr(Bm), Bm.stride(0), b_km, E._ptr(C),
+                                     C.stride(0), M, N, K, acc, E._ptr(row_map), E._ptr(k_map), E._ptr(ws),
+                                     ws.numel(), E._stream()))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("rows,M,N,K,b_km", [(3000, 1000, 512, 2048, 1), (3000, 1000, 2048, 512, 0),
+                                             (500, 77, 96, 36, 0), (200, 200, 512, 1536, 1), (64, 1, 128, 64, 1)])
+def test_gemm_row_map(cuda, rows, M, N, K, b_km):
+    """Product over a scattered subset of rows: reads A[map[m]], writes C[map[m]], leaves the other rows alone."""
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(1)
+    A = torch.randn(rows, K, device=cuda)
+    W = torch.randn(K, N, device=cuda) if b_km else torch.randn(N, K, device=cuda)
+    idx = torch.randperm(rows, device=cuda)[:M].sort().values.int()
+    C = torch.full((rows, N), 7.0, device=cuda)
+    _gemm_mapped(lib, A, 0, W, b_km, C, M, N, K, row_map=idx)
+    Wd = W.double() if b_km else W.double().t()
+    ref = torch.full((rows, N), 7.0, device=cuda, dtype=torch.float64)
+    ref[idx.long()] = A[idx.long()].double() @ Wd
+    assert torch.allclose(C.double(), ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
+    untouched = torch.ones(rows, dtype=torch.bool, device=cuda)
+    untouched[idx.long()] = False
+    assert torch.equal(C[untouched], torch.full_like(C[untouched], 7.0))
+    _gemm_mapped(lib, A, 0, W, b_km, C, M, N, K, acc=1, row_map=idx)       # accumulate
+    ref[idx.long()] += A[idx.long()].double() @ Wd
+    assert torch.allclose(C.double(), ref, rtol=1e-5, atol=2e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("rows,K,M,N", [(9000, 5003, 2048, 512), (300, 123, 128, 64), (40, 16, 512, 512),
+                                        (5000, 4096, 1536, 128), (100, 1, 64, 64)])
+def test_gemm_k_map(cuda, rows, K, M, N):
+    """Weight-gradient shape summed over a scattered subset of rows (ragged K, split K)."""
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(2)
+    dY = torch.randn(rows, M, device=cuda)
+    X = torch.randn(rows, N, device=cuda)
+    idx = torch.randperm(rows, device=cuda)[:K].sort().values.int()
+    C = torch.full((M, N), float("nan"), device=cuda)
+    _gemm_mapped(lib, dY, 1, X, 1, C, M, N, K, k_map=idx)
+    ref = dY[idx.long()].double().t() @ X[idx.long()].double()
+    assert torch.allclose(C.double(), ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
+    _gemm_mapped(lib, dY, 1, X, 1, C, M, N, K, acc=1, k_map=idx)
+    assert torch.allclose(C.double(), 2 * ref, rtol=1e-5, atol=2e-4 * K ** 0.5)
+
+
 def test_gemm_asymmetric_exact(cuda):
     """A = I with an asymmetric integer B catches swapped row/col maps."""
     from dvae_amd._lib import load
