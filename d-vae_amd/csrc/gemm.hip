@@ -30,6 +30,8 @@
 
 static int g_splitk_blocks = 768;   // tuning knob: workgroups a split-K launch aims for
 static int g_force_prio = -1;       // tuning knob: -1 as requested by the caller, 0/1 override
+static int g_force_splits = 0;      // lab knob: split-K factor for every launch (0 = automatic)
+extern "C" int dvae_gemm_force_splits(int v) { g_force_splits = v; return 0; }
 static int g_dbg = 0;
 extern "C" int dvae_gemm_dbg(int v) { g_dbg = v; return 0; }
 static int g_variant = 0;           // lab knob: 0 default (k-tile 16), 3 k-tile 32
@@ -444,6 +446,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     // loop at one workgroup per CU, is latency-bound -- spread K over the idle CUs
     splits = min(cdiv(256, p.nblk), d.K / 128);
   }
+  if (g_force_splits > 0 && ws) splits = g_force_splits;
   if (d.row_map) splits = 1;   // the slab reduction does not scatter rows
   if (splits > 1) {
     const size_t slab = (size_t)d.M * d.N * sizeof(float);

@@ -86,6 +86,7 @@ int dvae_gemm_f32_mapped(const float* A, int lda, int a_kmajor, const float* B, 
  * out12[6] (the unused layout slot) = wall milliseconds during which at least
  * one GEMM launch was running (launches on the two streams overlap). */
 int dvae_gemm_force_tile(int mode);   /* tuning knob: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
+int dvae_gemm_force_splits(int v);     /* lab knob: split-K factor of every launch (0 = automatic) */
 int dvae_gemm_variant(int v);          /* lab knob: force a tile shape (0 = automatic) */
 int dvae_gemm_dbg(int bits);           /* lab knob: 1 skip the epilogue stores, 2 skip reloads (timing ablations) */
 int dvae_gemm_tune(int splitk_blocks, int force_prio);   /* tuning knobs: workgroups a split-K launch aims for

@@ -58,3 +58,65 @@ def test_dp_sum_allreduce_equals_big_batch():
         mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         assert ret['grad_err'] < 1e-5, ret['grad_err']
         assert ret['loss_err'] < 1e-6, ret['loss_err']
+
+
+def test_balanced_ranges():
+    """Ragged batches are split by summed nodes + edges, contiguously, every rank non-empty."""
+    sys.path.insert(0, ROOT)
+    from dvae_amd import dp
+    cost = torch.tensor([1.0, 1, 1, 1, 10, 1, 1, 1, 1, 10])
+    r = dp.balanced_ranges(cost, 2)
+    assert r[0][0] == 0 and r[-1][1] == 10 and r[0][1] == r[1][0]
+    s0, s1 = float(cost[r[0][0]:r[0][1]].sum()), float(cost[r[1][0]:r[1][1]].sum())
+    assert abs(s0 - s1) <= 10.0 and min(s0, s1) >= 8.0
+    # more ranks than cost mass: still ordered, covering, non-empty
+    r = dp.balanced_ranges(torch.tensor([100.0, 1, 1, 1]), 4)
+    assert [hi - lo for lo, hi in r] == [1, 1, 1, 1]
+    r = dp.balanced_ranges(torch.tensor([1.0, 1, 1, 100]), 4)
+    assert [hi - lo for lo, hi in r] == [1, 1, 1, 1]
+    g = torch.rand(64, generator=torch.Generator().manual_seed(0)) * 100
+    r = dp.balanced_ranges(g, 8)
+    sums = [float(g[lo:hi].sum()) for lo, hi in r]
+    assert r[0][0] == 0 and r[-1][1] == 64 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert max(sums) - min(sums) <= 2.0 * float(g.max())
+    # the batch helper: ragged -> by cost, dense -> by count
+    import dvae_amd
+    gg, xx, sizes = dvae_amd.synth.ragged_dags(12, 4, 3, nmin=3, nmax=20)
+    full = {'graph': gg, 'node_encoding': xx, 'sizes': sizes}
+    parts = [dp.shard_batch(full, k, 3) for k in range(3)]
+    assert sum(p['graph'].shape[0] for p in parts) == 12
+    assert torch.equal(torch.cat([p['sizes'] for p in parts]), sizes)
+    costs = [float(dp.graph_cost(p).sum()) for p in parts]
+    assert max(costs) - min(costs) <= float(dp.graph_cost(full).max()) * 2
+    dense = {'graph': gg, 'node_encoding': xx}
+    assert [dp.shard_batch(dense, k, 3)['graph'].shape[0] for k in range(3)] == [4, 4, 4]
+
+
+def _map_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dvae_amd import dp
+    z = torch.arange(7 * 3, dtype=torch.float32).view(7, 3)          # 7 rows over 2 ranks: 4 + 3
+    seen = []
+
+    def fn(zz):
+        seen.append(zz.shape[0])
+        return zz * 2.0, zz.sum(1).long()
+    a, b = dp.sharded_map(fn, dist, z)
+    one = dp.sharded_map(lambda zz: zz + 1.0, dist, z)
+    ret[rank] = (seen[0], bool(torch.equal(a, z * 2.0)), bool(torch.equal(b, z.sum(1).long())),
+                 bool(torch.equal(one, z + 1.0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_map_gathers_in_row_order():
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_map_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert ret[0] == (4, True, True, True), ret[0]
+        assert ret[1] == (3, True, True, True), ret[1]
