@@ -12,7 +12,7 @@ from helpers import close_scaled, fill_weights, oracle_sd
 pytestmark = pytest.mark.gpu
 
 CASES = {
-    # name: (mod, bidir, shared, H, N, C, B, p, chain)
+    # name: (mod, bidir, shared, H, N, C, B, p, chain[, fix_orphans])
     "none_uni_h64": (None, False, False, 64, 8, 8, 12, 0.4, False),
     "none_bidir_h64": (None, True, False, 64, 7, 5, 9, 0.4, False),
     "bn_bidir_shared_h64": ("bn", True, True, 64, 10, 10, 6, 0.3, False),
@@ -20,16 +20,20 @@ CASES = {
     "none_bidir_h501": (None, True, False, 501, 8, 8, 6, 0.4, False),
     "bn_uni_h501": ("bn", False, False, 501, 10, 10, 5, 0.3, False),
     "none_uni_h128_n20": (None, False, False, 128, 20, 6, 5, 0.15, False),
+    # source nodes other than node 0 (level 0 holds several nodes of a graph; their k = 0 rows are scored)
+    "none_uni_h64_orphans": (None, False, False, 64, 9, 6, 10, 0.25, False, False),
+    "none_bidir_h64_orphans": (None, True, False, 64, 8, 5, 7, 0.2, False, False),
 }
 
 
 def _make(case, cuda):
     import dvae_amd
-    mod, bidir, shared, H, N, C, B, p, chain = CASES[case]
+    mod, bidir, shared, H, N, C, B, p, chain = CASES[case][:9]
+    fix_orphans = CASES[case][9] if len(CASES[case]) > 9 else True
     hp = Namespace(dataset_file=None, mod=mod, bidirectional=bidir, num_classes=C, max_seq=N,
                    same_mapper_gater=shared, hidden_state_size=H)
     model = fill_weights(dvae_amd.Dvae(hp), seed=11).to(cuda)
-    g, x = dvae_amd.synth.random_dags(B, N, C, p, seed=5, chain=chain)
+    g, x = dvae_amd.synth.random_dags(B, N, C, p, seed=5, chain=chain, fix_orphans=fix_orphans)
     gen = torch.Generator().manual_seed(9)
     eps = torch.randn(B, 56, generator=gen)
     return model, g, x, eps
