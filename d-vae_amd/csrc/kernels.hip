@@ -1108,7 +1108,8 @@ int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int
 int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
                const float* b2, float* edge_logits, int EHP, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
-  const int grid = std::min(cdiv(R, 4), 4096);
+  static const int cap = getenv("DVAE_PAIR_FWD_GRID") ? atoi(getenv("DVAE_PAIR_FWD_GRID")) : 4096;   // lab
+  const int grid = std::min(cdiv(R, 4), cap);
   VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, A, Bq, Cq, w2,
                                        b2, edge_logits));
   DVAE_LAUNCH_CHECK();
@@ -1149,7 +1150,8 @@ int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int*
   static const bool force_lds = getenv("DVAE_PAIR_LDS") != nullptr;   // lab: same-box A-B
   const bool reg = sv.N <= 8 && !force_lds;
   const size_t lds = reg ? 0 : (size_t)sv.N * EHP * sizeof(float);
-  grid = std::min(sv.B, reg ? 1024 : 512);
+  static const int cap = getenv("DVAE_PAIR_BWD_GRID") ? atoi(getenv("DVAE_PAIR_BWD_GRID")) : 1024;   // lab
+  grid = std::min(sv.B, reg ? cap : 512);
   grid = (int)std::min<size_t>(grid, part_floats / per);
 #define PAIR_FUSED(V)                                                                                          \
   if (reg)                                                                                                     \
