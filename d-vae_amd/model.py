@@ -292,6 +292,23 @@ class Dvae(nn.Module):
             recon_acc = reconstruction_accuracy(X['node_encoding'], X['graph'], gen_nodes, gen_edges)
             return {'recon_acc': recon_acc}
 
+    def generation_eval(self, num_samples=None, z=None, train_batch=None, is_stochastic=False, task_type='enas',
+                        dist=None):
+        """Addition (not in the reference; BASELINE config 5's validity/novelty path): decode
+        ``num_samples`` draws from the prior N(0,I) -- or the given latents ``z`` -- and report
+        validity, uniqueness and (given the training graphs) novelty of the decoded DAGs
+        (definitions in metrics.py).  ``dist``: shard the decode over the ranks (dp.predict_sharded)."""
+        from . import dp, metrics
+        dev = next(self.parameters()).device
+        if z is None:
+            z = torch.randn(int(num_samples), self.decoder.lin1.in_features, device=dev)
+        with torch.no_grad():
+            edges, onehots = dp.predict_sharded(self.decoder, z, dist, is_stochastic=is_stochastic)
+        te = tx = None
+        if train_batch is not None:
+            te, tx = train_batch['graph'], train_batch['node_encoding']
+        return metrics.generation_report(edges, onehots, te, tx, task_type)
+
     # -- fused train step (no autograd graph) --------------------------------------
     def _flat_grads(self):
         """Persistent flat gradient buffers (one per module) with p.grad installed

@@ -175,3 +175,44 @@ def test_shard_range():
         assert got[0][0] == 0 and got[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
         assert max(h - l for l, h in got) - min(h - l for l, h in got) <= 1
+
+
+def test_generation_metrics_on_real_and_broken_graphs():
+    """validity / uniqueness / novelty (additions, d-vae_amd/metrics.py): every real ENAS row of
+    the fixture is valid by the loader's own construction rules; targeted defects are caught."""
+    import os
+    import numpy as np
+    from dvae_amd import data, metrics
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    r = np.load(os.path.join(gold, "enas_rows.npz"))
+    enc = [data.encode_structure(data.parse_line(str(ln))[0], 'enas') for ln in r["lines"]]
+    E = torch.stack([g for g, _ in enc])
+    X = torch.stack([x for _, x in enc])
+    assert metrics.dag_validity(E, X, 'enas').all()
+    assert metrics.uniqueness(E, X) == 1.0
+    assert metrics.novelty(E, X, E, X) == 0.0
+    assert metrics.novelty(E, X, E[:4], X[:4]) == 0.5
+    N, C = X.shape[1], X.shape[2]
+    bad_e, bad_x = E[:6].clone(), X[:6].clone()
+    bad_e[0, 3, 2] = 0.0                                   # chain edge 2->3 missing
+    bad_x[1, 4] = 0.0; bad_x[1, 4, C - 2] = 1.0            # a second start token
+    bad_e[2, 2, 5] = 1.0                                   # entry above the diagonal
+    bad_e[3, N - 1, :] = 0.0                               # end node without predecessor
+    bad_x[4, 2] = 0.0                                      # node without a type
+    col = bad_e[5, :, 6].clone(); bad_e[5, :, 6] = 0.0     # node 6 feeds nobody
+    assert col.sum() > 0
+    ok = metrics.dag_validity(bad_e, bad_x, 'enas')
+    assert ok.tolist() == [False] * 6
+    rep = metrics.generation_report(torch.cat([E, bad_e]), torch.cat([X, bad_x]), E[:2], X[:2])
+    assert abs(rep['validity'] - 8 / 14) < 1e-6 and rep['uniqueness'] == 1.0 and abs(rep['novelty'] - 0.75) < 1e-6
+    # duplicates lower uniqueness; keys do not depend on the device or on batch position
+    assert metrics.uniqueness(torch.cat([E, E[:2]]), torch.cat([X, X[:2]])) == 0.8
+    assert torch.equal(metrics.graph_keys(E[3:5], X[3:5]), metrics.graph_keys(E, X)[3:5])
+    # bn: variable types must be distinct
+    g = torch.zeros(1, 5, 5); x = torch.zeros(1, 5, 5)
+    for i in range(1, 5):
+        g[0, i, i - 1] = 1.0
+    x[0, 0, 3] = 1.0; x[0, 4, 4] = 1.0; x[0, 1, 0] = 1.0; x[0, 2, 1] = 1.0; x[0, 3, 2] = 1.0
+    assert metrics.dag_validity(g, x, 'bn').all()
+    x[0, 3] = 0.0; x[0, 3, 1] = 1.0
+    assert not metrics.dag_validity(g, x, 'bn').any()
