@@ -216,3 +216,76 @@ def test_generation_metrics_on_real_and_broken_graphs():
     assert metrics.dag_validity(g, x, 'bn').all()
     x[0, 3] = 0.0; x[0, 3, 1] = 1.0
     assert not metrics.dag_validity(g, x, 'bn').any()
+
+
+def test_checkpoint_roundtrip_by_key_name(tmp_path):
+    """Lightning-layout checkpoints ({'state_dict': ...}, prediction.py:14-22): saved, loaded with
+    weights_only=True, matched by the reference's parameter names."""
+    from argparse import Namespace
+    import dvae_amd
+    from dvae_amd import trainer
+    hp = Namespace(dataset_file=None, mod=None, bidirectional=True, num_classes=5, max_seq=6, hidden_state_size=16)
+    a, b = dvae_amd.Dvae(hp), dvae_amd.Dvae(hp)
+    (opt,), (sched,) = a.configure_optimizers()
+    path = trainer.save_checkpoint(str(tmp_path / "run" / "_ckpt_epoch_3.ckpt"), a, opt, sched, epoch=3)
+    ck = trainer.load_checkpoint(path, b)
+    assert ck['epoch'] == 3 and set(ck) >= {'state_dict', 'optimizer_states', 'lr_schedulers'}
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    # a bare state_dict loads too; a missing key is an error when strict
+    torch.save(a.state_dict(), str(tmp_path / "bare.pt"))
+    trainer.load_checkpoint(str(tmp_path / "bare.pt"), b)
+    sd = dict(a.state_dict()); sd.pop(next(iter(sd)))
+    torch.save({'state_dict': sd}, str(tmp_path / "short.ckpt"))
+    with pytest.raises(RuntimeError):
+        trainer.load_checkpoint(str(tmp_path / "short.ckpt"), b)
+
+
+def test_trainer_loop_on_a_stub_model(tmp_path):
+    """The epoch loop over the Lightning-style hooks (train.py:39-47): optimizer steps, validation
+    mean, ReduceLROnPlateau on the validation loss, one checkpoint per epoch, resume."""
+    from dvae_amd import trainer
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.tensor([4.0]))
+            self.data = [{'graph': torch.ones(2, 1)} for _ in range(3)]
+
+        def training_step(self, batch, i):
+            loss = (self.w ** 2).sum() * batch['graph'].sum() / 2
+            v = float(loss)
+            return {'loss': loss, 'log': {'train/edge_loss': v, 'train/vertex_loss': 0.0, 'train/kl_loss': 0.0,
+                                          'train/loss': v}}
+
+        def validation_step(self, batch, i):
+            v = (self.w.detach() ** 2).sum()
+            return {'val_loss': v, 'val/edge_loss': v, 'val/vertex_loss': v * 0, 'val/kl_loss': v * 0}
+
+        def validation_end(self, outs):
+            m = torch.stack([o['val_loss'] for o in outs]).mean()
+            return {'avg_val_loss': m, 'log': {'val_loss': m}}
+
+        def configure_optimizers(self):
+            opt = torch.optim.SGD(self.parameters(), lr=0.1)
+            return [opt], [torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=0, factor=0.5)]
+
+        def train_dataloader(self):
+            return self.data
+
+        def val_dataloader(self):
+            return self.data[:2]
+
+    logs = []
+    m = Stub()
+    t = trainer.Trainer(max_epochs=3, save_dir=str(tmp_path), log=logs.append)
+    hist = t.fit(m)
+    assert [h['epoch'] for h in hist] == [0, 1, 2] and all(h['steps'] == 3 for h in hist)
+    assert hist[0]['train/loss'] > hist[1]['train/loss'] > hist[2]['train/loss']     # w shrinks every step
+    assert abs(hist[0]['val_loss'] - float(m.w ** 2) ) > 0 and hist[2]['val_loss'] < hist[0]['val_loss']
+    assert sorted(os.listdir(str(tmp_path))) == ['_ckpt_epoch_2.ckpt']              # older epochs removed
+    w_end = float(m.w)
+    m2 = Stub()
+    t2 = trainer.Trainer(max_epochs=4, save_dir=str(tmp_path), log=logs.append)
+    h2 = t2.fit(m2, resume_from=str(tmp_path / '_ckpt_epoch_2.ckpt'))
+    assert [h['epoch'] for h in h2] == [3] and float(m2.w) < w_end
