@@ -463,12 +463,18 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
 // between its per-level launches); the lower levels follow after the sweep.  One early chunk
 // only: per-level products were measured slower (small launches).  0 = no early chunk.
 // DVAE_WGRAD_SPLIT=<fraction of rows in the early chunk, 0 = off> (default 0.35).
+struct WgradSplitCfg {
+  double frac = getenv("DVAE_WGRAD_SPLIT") ? atof(getenv("DVAE_WGRAD_SPLIT")) : 0.35;
+  int min_rows = 16384;   // small batches: the split only adds launches
+};
+WgradSplitCfg g_wgrad_split;
+
 int wgrad_split_level(const dvae_dims& d, const Levels& lv, bool prefix, bool two_streams) {
-  static const double frac = getenv("DVAE_WGRAD_SPLIT") ? atof(getenv("DVAE_WGRAD_SPLIT")) : 0.35;
+  const double frac = g_wgrad_split.frac;
   if (!two_streams || frac <= 0.0 || d.mod != 0 || lv.nlev < 3) return 0;
   const int* cum = prefix ? lv.es : lv.ls;
   const int T = cum[lv.nlev];
-  if (T < 16384) return 0;   // small batches: the split only adds launches
+  if (T < g_wgrad_split.min_rows) return 0;
   int L0 = 0;
   for (int L = 1; L < lv.nlev; ++L)
     if ((double)(T - cum[L]) >= frac * T) L0 = L;
@@ -843,6 +849,14 @@ extern "C" int dvae_side_stream_create(void** stream_out, int* priority_out) {
 
 extern "C" int dvae_side_stream_destroy(void* stream) {
   if (stream) DVAE_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return DVAE_OK;
+}
+
+// tuning / test knob: share of a sweep's rows whose weight-gradient products start before the
+// sweep has finished (0 = none), and the row count below which there is no early chunk
+extern "C" int dvae_wgrad_split_tune(double frac, int min_rows) {
+  g_wgrad_split.frac = frac;
+  g_wgrad_split.min_rows = min_rows;
   return DVAE_OK;
 }
 

@@ -227,6 +227,10 @@ int dvae_decoder_bwd(const dvae_dims* d, const float* z, const float* x, const i
  * prefix rows from the per-type table when dvae_sched_types allows it (default 1).  Every
  * combination computes the same formulas (fp32 summation order may differ). */
 int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share);
+/* tuning / test knob: share of a sweep's rows whose weight-gradient products are issued on the
+ * side stream while the backward sweep is still running (default 0.35; 0 = none), and the row
+ * count below which a sweep has no early chunk (default 16384). */
+int dvae_wgrad_split_tune(double frac, int min_rows);
 
 /* Side stream for the *_fwd / *_bwd calls above (no counterpart in the reference).
  * It is created with the LOWEST scheduling priority the device offers, so that the

@@ -174,3 +174,28 @@ def test_trainer_fits_real_enas_rows(cuda, tmp_path, fused):
     torch.manual_seed(5); v1 = float(t.validate(model)['avg_val_loss'])
     torch.manual_seed(5); v2 = float(t.validate(again)['avg_val_loss'])
     assert abs(v1 - v2) <= 1e-6 * abs(v1)
+
+
+@pytest.mark.parametrize("bidir", [False, True])
+def test_early_weight_gradient_chunk(cuda, bidir):
+    """Weight-gradient products of the upper levels issued while the backward sweep still runs
+    (forced here at a small size; by default only sweeps of >= 16384 rows do it): the gradients
+    are those of the single pass after the sweep -- the loss is bit-identical (forward untouched),
+    the gradients differ by the order of two partial sums only."""
+    from dvae_amd import _lib
+    lib = _lib.load()
+    model, X, eps = _setup(cuda, 200, bidir=bidir)
+    try:
+        lib.dvae_wgrad_split_tune(0.0, 16384)
+        ref = _step(model, X, eps)
+        lib.dvae_wgrad_split_tune(0.5, 0)
+        out = _step(model, X, eps)
+        lib.dvae_wgrad_split_tune(0.2, 0)
+        out2 = _step(model, X, eps)
+    finally:
+        lib.dvae_wgrad_split_tune(0.35, 16384)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out2[0], ref[0])
+    for o in (out, out2):
+        rel = float((o[1] - ref[1]).norm() / ref[1].norm())
+        assert rel <= 1e-5, "gradients: relative L2 error %.3e" % rel
+        close_scaled(o[1], ref[1], tol=1e-4, what="gradients")
