@@ -624,7 +624,6 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
                                 const void* sched, const int* info, const float* P, void* ws,
                                 float* edge_logits, float* type_logits, float* states, void* stream,
                                 void* side_stream) {
-  (void)sizes;
   DVAE_REQUIRE(dp && z && x && sched && P && ws && edge_logits && type_logits, "decoder_fwd: null pointer");
   const dvae_dims& d = *dp;
   DVAE_TRY(check_info(d, info));
@@ -702,7 +701,7 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
     DVAE_TRY(k_rows_to_dense(S, R, w.s.Hn, HP, states, d.N, d.H, st));
   }
-  DVAE_TRY(k_pair_fwd(sv, ts, R, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
+  DVAE_TRY(k_pair_fwd(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
   DVAE_TRY(ev.edge(sd, st));
   return DVAE_OK;
 }

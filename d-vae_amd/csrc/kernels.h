@@ -89,8 +89,8 @@ int k_graph_state_fwd(const SchedDir& S, int R, int N, int mod, const float* Hn,
                       int HP, hipStream_t st);
 int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int* sizes, const float* DGS,
                       float* DHn, float* dh0, int HP, hipStream_t st);
-int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
-               const float* b2, float* edge_logits, int EHP, hipStream_t st);
+int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,
+               const float* Cq, const float* w2, const float* b2, float* edge_logits, int EHP, hipStream_t st);
 // DA [RH][EHP]; out = dw2 [EHP] | db2 [4]
 int k_pair_bwd_a(const SchedView& sv, const TypeShare& ts, int R, int RH, const float* A, const float* Bq, const float* Cq,
                  const float* w2, const float* d_edge, float* DA, float* out, float* part,

@@ -608,16 +608,89 @@ __global__ void add_rows_kernel(float* __restrict__ dst, int ldd, const float* _
 //   logit(i,j) = w2 . relu(A[prow(i,k)] + Bq[j] (+ Cq[b])) + b2,
 //   k = number of predecessors of i with index above j.  One wave per row.
 // ---------------------------------------------------------------------------
+// all pairs (i, j < i) of node row r, by one wave
 template <int VPL>
-__global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, TypeShare ts, int R, const float* __restrict__ A,
+__device__ __forceinline__ void pair_fwd_row(const SchedView& sv, const TypeShare& ts, int R, int r, int lane,
+                                             const float4 (&wv)[VPL], float bias2, const float* __restrict__ A,
+                                             const float* __restrict__ Bq, const float* __restrict__ Cq,
+                                             float* __restrict__ edge_logits) {
+  constexpr int EHP = VPL * 256;
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N;
+  const int i = S.row_node[r];
+  if (i == 0) return;
+  const int b = S.row_graph[r];
+  const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+  int t = 0, cur = -1;
+  int next_pred = deg > 0 ? S.row_node[S.csr_idx[p]] : -1;
+  float4 a[VPL], c[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) c[v] = Cq ? ld4(Cq + (size_t)b * EHP + (lane + 64 * v) * 4) : zero4();
+  for (int j = i - 1; j >= 0; --j) {
+    while (t < deg && next_pred > j) {
+      ++t;
+      next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
+    }
+    if (t != cur) {
+      const float* ar = a_row(sv, ts, A, EHP, R, r, t);
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+        a[v] = add4(ld4(ar + (lane + 64 * v) * 4), c[v]);
+      cur = t;
+    }
+    const size_t rj = S.node2row[b * N + j];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const float4 q = add4(a[v], ld4(Bq + rj * EHP + (lane + 64 * v) * 4));
+      s = fmaf(wv[v].x, fmaxf(q.x, 0.f), s);
+      s = fmaf(wv[v].y, fmaxf(q.y, 0.f), s);
+      s = fmaf(wv[v].z, fmaxf(q.z, 0.f), s);
+      s = fmaf(wv[v].w, fmaxf(q.w, 0.f), s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) edge_logits[((size_t)b * N + i) * N + j] = s + bias2;
+  }
+}
+
+// One workgroup per graph (grid-stride); its four waves share the graph's node rows so that the Bq
+// rows, which every later node of the graph reads again, stay in this CU's L1 / this XCD's L2.
+// Wave w takes the node pairs {n-1-k, k}, k = w, w+4, ..: n-1 pair evaluations each, balanced.
+template <int VPL>
+__global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, TypeShare ts, int R, const int* __restrict__ sizes,
+                                                       const float* __restrict__ A,
                                                        const float* __restrict__ Bq,
                                                        const float* __restrict__ Cq,
                                                        const float* __restrict__ w2,
                                                        const float* __restrict__ b2,
                                                        float* __restrict__ edge_logits) {
-  constexpr int EHP = VPL * 256;
   const SchedDir& S = sv.dir[0];
   const int N = sv.N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 wv[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) wv[v] = ld4(w2 + (lane + 64 * v) * 4);
+  const float bias2 = b2[0];
+  for (int b = blockIdx.x; b < sv.B; b += gridDim.x) {
+    const int n = graph_size(sizes, b, N);
+    for (int k = wave; 2 * k <= n - 1; k += 4) {
+      const int hi = n - 1 - k;
+      pair_fwd_row<VPL>(sv, ts, R, S.node2row[b * N + hi], lane, wv, bias2, A, Bq, Cq, edge_logits);
+      if (k != hi && k > 0)
+        pair_fwd_row<VPL>(sv, ts, R, S.node2row[b * N + k], lane, wv, bias2, A, Bq, Cq, edge_logits);
+    }
+  }
+}
+
+// the same with one wave per node row in row order (rows of one level side by side)
+template <int VPL>
+__global__ __launch_bounds__(256) void pair_fwd_rows_kernel(SchedView sv, TypeShare ts, int R,
+                                                            const float* __restrict__ A,
+                                                            const float* __restrict__ Bq,
+                                                            const float* __restrict__ Cq,
+                                                            const float* __restrict__ w2,
+                                                            const float* __restrict__ b2,
+                                                            float* __restrict__ edge_logits) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
@@ -625,42 +698,7 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, TypeShare t
 #pragma unroll
   for (int v = 0; v < VPL; ++v) wv[v] = ld4(w2 + (lane + 64 * v) * 4);
   const float bias2 = b2[0];
-  for (int r = wid; r < R; r += nw) {
-    const int i = S.row_node[r];
-    if (i == 0) continue;
-    const int b = S.row_graph[r];
-    const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
-    int t = 0, cur = -1;
-    int next_pred = deg > 0 ? S.row_node[S.csr_idx[p]] : -1;
-    float4 a[VPL], c[VPL];
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) c[v] = Cq ? ld4(Cq + (size_t)b * EHP + (lane + 64 * v) * 4) : zero4();
-    for (int j = i - 1; j >= 0; --j) {
-      while (t < deg && next_pred > j) {
-        ++t;
-        next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
-      }
-      if (t != cur) {
-        const float* ar = a_row(sv, ts, A, EHP, R, r, t);
-#pragma unroll
-        for (int v = 0; v < VPL; ++v)
-          a[v] = add4(ld4(ar + (lane + 64 * v) * 4), c[v]);
-        cur = t;
-      }
-      const size_t rj = S.node2row[b * N + j];
-      float s = 0.f;
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const float4 q = add4(a[v], ld4(Bq + rj * EHP + (lane + 64 * v) * 4));
-        s = fmaf(wv[v].x, fmaxf(q.x, 0.f), s);
-        s = fmaf(wv[v].y, fmaxf(q.y, 0.f), s);
-        s = fmaf(wv[v].z, fmaxf(q.z, 0.f), s);
-        s = fmaf(wv[v].w, fmaxf(q.w, 0.f), s);
-      }
-      s = wave_sum(s);
-      if (lane == 0) edge_logits[((size_t)b * N + i) * N + j] = s + bias2;
-    }
-  }
+  for (int r = wid; r < R; r += nw) pair_fwd_row<VPL>(sv, ts, R, r, lane, wv, bias2, A, Bq, Cq, edge_logits);
 }
 
 // one wave per prefix row p = (i,k): pairs j in [u_{k+1}, u_k - 1]
@@ -1105,13 +1143,20 @@ int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int
   return DVAE_OK;
 }
 
-int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const float* A, const float* Bq, const float* Cq, const float* w2,
-               const float* b2, float* edge_logits, int EHP, hipStream_t st) {
+int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,
+               const float* Cq, const float* w2, const float* b2, float* edge_logits, int EHP, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
+  static const bool by_rows = getenv("DVAE_PAIR_FWD_ROWS") != nullptr;   // lab: the row-order mapping
   static const int cap = getenv("DVAE_PAIR_FWD_GRID") ? atoi(getenv("DVAE_PAIR_FWD_GRID")) : 4096;   // lab
-  const int grid = std::min(cdiv(R, 4), cap);
-  VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, A, Bq, Cq, w2,
-                                       b2, edge_logits));
+  if (by_rows) {
+    const int grid = std::min(cdiv(R, 4), cap);
+    VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_rows_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, A, Bq, Cq,
+                                         w2, b2, edge_logits));
+  } else {
+    const int grid = std::min(sv.B, cap);
+    VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, sizes, A, Bq,
+                                         Cq, w2, b2, edge_logits));
+  }
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
