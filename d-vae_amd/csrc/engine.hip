@@ -22,7 +22,7 @@ struct LevelCfg {
   int fused_gm_min_rows; int fused_gru; int type_share;
   LevelCfg() {
     type_share = getenv("DVAE_NO_TYPE_SHARE") ? 0 : 1;
-    fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : 2048;
+    fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : getenv("DVAE_FUSED_GM_MIN") ? atoi(getenv("DVAE_FUSED_GM_MIN")) : 2048;
     fused_gru = (!getenv("DVAE_UNFUSED") && getenv("DVAE_FUSED_GRU")) ? 1 : 0;
   }
 };
