@@ -392,7 +392,7 @@ struct ProfState {
 };
 ProfState g_prof;
 
-std::mutex g_prof_mu;   // micro-batches are launched from several host threads
+std::mutex g_prof_mu;   // callers may launch from several host threads
 
 GemmProf* prof_begin(int variant, double flops, hipStream_t st) {
   if (!g_prof.on) return nullptr;
