@@ -255,7 +255,8 @@ int check_info(const dvae_dims& d, const int* info) {
 // every node encoding is one-hot (dvae_sched_types) and there are levels >= 1: the decoder's
 // k = 0 prefix rows of those levels are shared by node type (sched.h TypeShare)
 bool type_shared(const dvae_dims& d, const int* info, const Levels& lv) {
-  return g_level_cfg.type_share && info[5] == 1 && d.mod == 0 && lv.nlev > 1 && lv.R > lv.ls[1];
+  (void)d;
+  return g_level_cfg.type_share && info[5] == 1 && lv.nlev > 1 && lv.R > lv.ls[1];
 }
 
 // node rows that need a W1b product (Bq = W1b.hd + b1): all of them, minus the last level when it
@@ -315,7 +316,7 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       DVAE_TRY(gru_rows(0, R));
     } else {
       DVAE_TRY(gru_rows(0, z1));
-      DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
+      if (!k0_shared) DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
       DVAE_TRY(gru_rows(R, b.RH));
     }
     if (hook) DVAE_TRY(hook(0, b.RH, 0, R));
@@ -364,7 +365,12 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     return g.nn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DH + (size_t)p0 * HP, HP, p1 - p0, HP, 3 * HP, 1);
   };
   if (d.mod == 1) {
-    DVAE_TRY(k_gru_bwd(S, 0, b.RH, b, HP, st));
+    if (b.prefix && k0_shared) {   // the k = 0 rows [z1,R) are handled per type by the caller
+      DVAE_TRY(k_gru_bwd(S, 0, z1, b, HP, st));
+      DVAE_TRY(k_gru_bwd(S, R, b.RH, b, HP, st));
+    } else {
+      DVAE_TRY(k_gru_bwd(S, 0, b.RH, b, HP, st));
+    }
     if (!b.prefix) {
       DVAE_TRY(dagg_gemm(0, R));
     } else {
@@ -664,7 +670,8 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
   LevelHook hook = [&](int p0, int p1, int ns, int ne) -> int {
     DVAE_TRY(ev.edge(st, sd));
     // k = 0 rows, then edge rows
-    const int n0 = (skip0 && p0 == 0) ? std::min(z1, p1) : p0, n1 = std::min(p1, R);
+    // (type-shared k = 0 rows [z1,R) come from the per-type table, not from a product)
+    const int n0 = (skip0 && p0 == 0) ? std::min(z1, p1) : p0, n1 = std::min(p1, typed ? z1 : R);
     if (n1 > n0)
       DVAE_TRY(gs.nt(w.s.HV + (size_t)n0 * HP, HP, P + L.W1a, HP, w.A + (size_t)n0 * EHP, EHP, n1 - n0, EHP, HP));
     const int e0 = std::max(p0, R), e1 = p1;

@@ -12,9 +12,9 @@ from helpers import close_scaled, fill_weights
 pytestmark = pytest.mark.gpu
 
 
-def _setup(cuda, B, bidir=False, N=8, C=8, H=501, seed=3):
+def _setup(cuda, B, bidir=False, N=8, C=8, H=501, seed=3, mod=None):
     import dvae_amd
-    hp = Namespace(dataset_file=None, mod=None, bidirectional=bidir, num_classes=C, max_seq=N, hidden_state_size=H)
+    hp = Namespace(dataset_file=None, mod=mod, bidirectional=bidir, num_classes=C, max_seq=N, hidden_state_size=H)
     model = fill_weights(dvae_amd.Dvae(hp), seed).to(cuda)
     g, x = dvae_amd.synth.random_dags(B, N, C, 0.35, seed=21, chain=True)
     eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(4))
@@ -76,12 +76,14 @@ def test_prepared_schedule_rejects_bad_graph(cuda):
         model.loss_and_grad(bad, eps=eps, sched=sched)
 
 
-def test_type_shared_rows_match_per_row(cuda):
+@pytest.mark.parametrize("mod", [None, "bn"])
+def test_type_shared_rows_match_per_row(cuda, mod):
     """One-hot node encodings: the decoder's (type, h_in = 0) prefix rows come from a C-row table
-    (dvae_sched_types / TypeShare) -- same results as computing every row."""
+    (dvae_sched_types / TypeShare), and add_edge's first layer runs on the scored prefix rows only
+    -- same results as computing every row (dvae_level_tune(.., 0) turns both off)."""
     from dvae_amd import _lib
     lib = _lib.load()
-    model, X, eps = _setup(cuda, 300)
+    model, X, eps = _setup(cuda, 300, mod=mod, H=501 if mod is None else 128)
     assert model._schedule(X).onehot
     try:
         lib.dvae_level_tune(2048, 0, 0)
