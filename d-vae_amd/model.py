@@ -145,7 +145,7 @@ class Decoder(nn.Module):
                 'graph has %d nodes but the position encoding has %d columns' % (g.shape[1], self.seq_len)
         assert z.shape == (g.shape[0], self.latent_space_dim), 'z must be [B,%d]' % self.latent_space_dim
         if sched is None:
-            sched = E.Schedule(g, sizes, want_reverse=False)
+            sched = E.Schedule(g, sizes, want_reverse=False, x=x)
         return E.DecoderFn.apply(self, sched, z, E._f32c(x), *self.hip_params())
 
     def node_states(self, z, X):
