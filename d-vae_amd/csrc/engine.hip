@@ -41,6 +41,7 @@ constexpr size_t GEMM_WS_BYTES = (size_t)96 << 20;
 
 size_t part_floats_for(const dvae_dims& d) {
   size_t m = (size_t)(d.EHP + 4) * (2048 + 64);   // pair_bwd_a: one partial per wave + the group sums of its 2-stage reduction
+  m = std::max(m, (size_t)(2 * d.EHP + 4) * (1024 + 40));   // pair_bwd_fused: [db1 | dw2 | db2] per block
   m = std::max(m, (size_t)d.EHP * 512);
   return m;
 }
@@ -744,7 +745,9 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(k_dense_to_rows(S, R, d_type, d.N, d.C, w.DTL, d.CP, av));
   DVAE_TRY(gav.nn(w.DTL, d.CP, P + L.Wv2, d.VHP, w.DVH, d.VHP, R, d.VHP, d.CP));
-  DVAE_TRY(k_relu_bwd(w.DVH, w.VH, (size_t)R * d.VHP, av));
+  // ReLU backward and add_vertex.0's bias gradient in one pass over DVH
+  DVAE_TRY(k_relu_bwd_colsum(w.DVH, w.VH, d.VHP, R, d.VHP, Gp + L.bv1, av_main ? msc.part : ssc.part,
+                             av_main ? msc.part_floats : ssc.part_floats, av));
   // the graph state seen by add_vertex at node i is the state of node i-1 (bn: all earlier
   // nodes), which may sit in any level: this product cannot follow the sweep level by level
   DVAE_TRY(gav.nn(w.DVH, d.VHP, P + L.Wv1, HP, w.DGS, HP, R, HP, d.VHP));
@@ -758,7 +761,6 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(gs.tn(w.DTL, d.CP, w.VH, d.VHP, Gp + L.Wv2, d.VHP, d.CP, d.VHP, R));
   DVAE_TRY(k_colsum(w.DTL, d.CP, R, d.CP, Gp + L.bv2, ssc.part, ssc.part_floats, sd));
   DVAE_TRY(gs.tn(w.DVH, d.VHP, w.GS, HP, Gp + L.Wv1, HP, d.VHP, HP, R));
-  DVAE_TRY(k_colsum(w.DVH, d.VHP, R, d.VHP, Gp + L.bv1, ssc.part, ssc.part_floats, sd));
 
   SweepW sw{gru_at(P + L.gru, HP, d.C), P + L.gm};
   const bool typed = type_shared(d, info, lv);
@@ -767,7 +769,9 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const bool scored = scored_rows_only(), skip0 = skip_level0(info);
   const int U = (scored && lv.as[d.N] <= lv.E) ? lv.as[d.N] : -1;   // scored edge rows (sv.a_rows), -1: all rows
   if (pair_bwd_fused_ok(d.N, EHP)) {
-    DVAE_TRY(k_pair_bwd_fused(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.w2, msc.part,
+    // its partial sums carry db1 (the column sums of DBq), dw2 and db2, adjacent in the packed layout
+    DVAE_REQUIRE(L.w2 == L.b1 + (size_t)EHP && L.b2 == L.w2 + (size_t)EHP, "decoder layout: b1 | w2 | b2 must be adjacent");
+    DVAE_TRY(k_pair_bwd_fused(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.b1, msc.part,
                               msc.part_floats, EHP, st));
   } else {
     DVAE_TRY(k_pair_bwd_a(sv, ts, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part,
@@ -793,7 +797,8 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   }
   const int Rb = bq_rows(info, lv);   // DBq rows beyond Rb are zero (no pair has them as candidate)
   DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, Rb));
-  DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
+  if (!pair_bwd_fused_ok(d.N, EHP))   // (the fused pair backward has summed db1 already)
+    DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
 
   // ---- add_edge input gradients, then the level sweep ----

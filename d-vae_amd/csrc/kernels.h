@@ -60,6 +60,8 @@ int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_
 // out[w] = sum_rows X[row][w]   (W % 4 == 0)
 int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
              hipStream_t st);
+int k_relu_bwd_colsum(float* D, const float* Y, int ld, int rows, int W, float* out, float* part,
+                      size_t part_floats, hipStream_t st);   // D *= (Y > 0), out = column sums of D
 
 // [B][N][W] API tensors <-> node-row tables
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st);

@@ -374,16 +374,29 @@ __global__ void build_px_kernel(SchedDir S, int R, int npos, int PP, float* __re
 }
 
 // part[chunk][w] = sum over the chunk's rows of X[row][w]: a block owns 64 columns x one
-// row chunk; 16 row lanes x 16 float4 columns, rows strided by 16, lanes folded in fixed order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc,
-                                                     int W, float* __restrict__ part) {
+// row chunk; 16 row lanes x 16 float4 columns, rows strided by 16, lanes folded in fixed order.
+// MASK: X *= (Y > 0) first, written back (ReLU backward and the bias gradient in one pass).
+template <bool MASK>
+__global__ __launch_bounds__(256) void colsum_kernel(float* __restrict__ X, const float* __restrict__ Y, int ld,
+                                                     int rows, int rpc, int W, float* __restrict__ part) {
   __shared__ float4 sh[16][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + cx * 4;
   const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
   float4 s = zero4();
   if (col < W)
-    for (int r = r0 + ry; r < r1; r += 16) s = add4(s, ld4(X + (size_t)r * ld + col));
+    for (int r = r0 + ry; r < r1; r += 16) {
+      float4 v = ld4(X + (size_t)r * ld + col);
+      if (MASK) {
+        const float4 y = ld4(Y + (size_t)r * ld + col);
+        v.x = y.x > 0.f ? v.x : 0.f;
+        v.y = y.y > 0.f ? v.y : 0.f;
+        v.z = y.z > 0.f ? v.z : 0.f;
+        v.w = y.w > 0.f ? v.w : 0.f;
+        st4(X + (size_t)r * ld + col, v);
+      }
+      s = add4(s, v);
+    }
   sh[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && col < W) {
@@ -839,11 +852,12 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
   const SchedDir& S = sv.dir[0];
   const int N = sv.N, B = sv.B;
   const int col0 = threadIdx.x * 4;
-  float4 wv[Q], dw[Q];
+  float4 wv[Q], dw[Q], dbs[Q];   // dbs: column sums of every DBq row = the gradient of add_edge.0's bias
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     wv[q] = ld4(w2 + col0 + 1024 * q);
     dw[q] = zero4();
+    dbs[q] = zero4();
   }
   float db = 0.f;
   constexpr int NR = NREG > 0 ? NREG : 1;
@@ -935,20 +949,31 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
         if (j < n) {
           float* dst = DBq + (size_t)S.node2row[b * N + j] * EHP;
 #pragma unroll
-          for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, dreg[j][q]);
+          for (int q = 0; q < Q; ++q) {
+            st4(dst + col0 + 1024 * q, dreg[j][q]);
+            dbs[q] = add4(dbs[q], dreg[j][q]);
+          }
         }
     } else {
       for (int j = 0; j < n; ++j) {
         float* dst = DBq + (size_t)S.node2row[b * N + j] * EHP;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) st4(dst + col0 + 1024 * q, ld4(dbq + (size_t)j * EHP + col0 + 1024 * q));
+        for (int q = 0; q < Q; ++q) {
+          const float4 v = ld4(dbq + (size_t)j * EHP + col0 + 1024 * q);
+          st4(dst + col0 + 1024 * q, v);
+          dbs[q] = add4(dbs[q], v);
+        }
       }
     }
   }
-  float* out = part + (size_t)blockIdx.x * (EHP + 4);
+  // one partial row per block, laid out as the packed gradient has them: [db1 | dw2 | db2]
+  float* out = part + (size_t)blockIdx.x * (2 * EHP + 4);
 #pragma unroll
-  for (int q = 0; q < Q; ++q) st4(out + col0 + 1024 * q, dw[q]);
-  if (threadIdx.x == 0) st4(out + EHP, make_float4(db, 0.f, 0.f, 0.f));
+  for (int q = 0; q < Q; ++q) {
+    st4(out + col0 + 1024 * q, dbs[q]);
+    st4(out + EHP + col0 + 1024 * q, dw[q]);
+  }
+  if (threadIdx.x == 0) st4(out + 2 * EHP, make_float4(db, 0.f, 0.f, 0.f));
 }
 
 #define VPL_DISPATCH(EHP, CALL)                                                   \
@@ -1047,8 +1072,9 @@ int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_
   return DVAE_OK;
 }
 
-int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
-             hipStream_t st) {
+namespace {
+int colsum_launch(float* X, const float* Y, int ld, int rows, int W, float* out, float* part, size_t part_floats,
+                  hipStream_t st) {
   DVAE_REQUIRE((W & 3) == 0 && (ld & 3) == 0, "colsum: widths must be multiples of 4");
   DVAE_REQUIRE(part_floats >= (size_t)W, "colsum: scratch too small");
   // enough chunks to fill the chip (column groups x chunks >= ~1024 blocks), at least 64 rows each
@@ -1057,9 +1083,22 @@ int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, s
   nch = (int)std::max<size_t>(1, std::min<size_t>(nch, part_floats / (size_t)W));
   const int rpc = std::max(1, cdiv(rows, nch));
   nch = std::max(1, cdiv(rows, rpc));
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, part);
+  if (Y) hipLaunchKernelGGL(colsum_kernel<true>, dim3(gx, nch), dim3(256), 0, st, X, Y, ld, rows, rpc, W, part);
+  else hipLaunchKernelGGL(colsum_kernel<false>, dim3(gx, nch), dim3(256), 0, st, X, Y, ld, rows, rpc, W, part);
   DVAE_LAUNCH_CHECK();
   return reduce_parts(part, nch, (size_t)W, out, (size_t)W, st);
+}
+}  // namespace
+
+int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
+             hipStream_t st) {
+  return colsum_launch(const_cast<float*>(X), nullptr, ld, rows, W, out, part, part_floats, st);
+}
+
+// D *= (Y > 0) in place and out[w] = sum over rows of the masked D: one pass over both tables
+int k_relu_bwd_colsum(float* D, const float* Y, int ld, int rows, int W, float* out, float* part,
+                      size_t part_floats, hipStream_t st) {
+  return colsum_launch(D, Y, ld, rows, W, out, part, part_floats, st);
 }
 
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st) {
@@ -1187,7 +1226,7 @@ int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int*
                      const float* Bq, const float* Cq, const float* w2, const float* d_edge, float* DA, float* DBq,
                      float* out, float* part, size_t part_floats, int EHP, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
-  const size_t per = (size_t)EHP + 4;
+  const size_t per = (size_t)2 * EHP + 4;   // [db1 | dw2 | db2], contiguous in the packed gradient too
   int grid = std::min(sv.B, 512);
   grid = (int)std::min<size_t>(grid, part_floats / per);
   DVAE_REQUIRE(grid >= 1, "pair_bwd_fused: scratch too small");
@@ -1197,7 +1236,8 @@ int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int*
   const size_t lds = reg ? 0 : (size_t)sv.N * EHP * sizeof(float);
   static const int cap = getenv("DVAE_PAIR_BWD_GRID") ? atoi(getenv("DVAE_PAIR_BWD_GRID")) : 1024;   // lab
   grid = std::min(sv.B, reg ? cap : 512);
-  grid = (int)std::min<size_t>(grid, part_floats / per);
+  grid = (int)std::min<size_t>(grid, part_floats / per * 32 / 33);   // room for the group sums of the 2-stage reduction
+  grid = std::max(grid, 1);
 #define PAIR_FUSED(V)                                                                                          \
   if (reg)                                                                                                     \
     hipLaunchKernelGGL((pair_bwd_fused_kernel<V, 8>), dim3(grid), dim3(256), 0, st, sv, ts, R, sizes, A, Bq, Cq, \
