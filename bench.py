@@ -127,15 +127,19 @@ def main():
     # the level schedule of batch i+1 is queued (own stream) as soon as step i has been
     # launched, as a prefetching data loader would: every step still builds one schedule
     # inside the timed region, but nobody waits for its host round trip
-    # (multi-GPU runs build it in-step: with RCCL's streams a prefetch stream would be the fifth
-    # stream of the process and the box gives a process 4 hardware queues)
+    # (multi-GPU runs queue it on the library's side stream at the start of the step: with RCCL's
+    # streams a prefetch stream would be the fifth stream of the process and the box gives a process
+    # 4 hardware queues)
     prepared = {}
-    prefetch = not args.no_prefetch and dist is None
+    prefetch = not args.no_prefetch
+    on_side = dist is not None     # with RCCL in the process: no third stream, the side stream builds it
 
     def step(i):
         sched = prepared.pop(i, None)
+        if prefetch and on_side:   # queued ahead of this step's own side-stream work (idle until the decoder starts)
+            prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True, on_side_stream=True)
         out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads, sched=sched)
-        if prefetch:
+        if prefetch and not on_side:
             prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True)
         opt.step()
         return out4

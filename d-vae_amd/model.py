@@ -322,18 +322,26 @@ class Dvae(nn.Module):
             self._flat = (key, fe, fd)
         return self._flat[1], self._flat[2]
 
-    def prepare(self, batch, resident=False):
+    def prepare(self, batch, resident=False, on_side_stream=False):
         """Queue the level-schedule build of a FUTURE batch on a stream of its own and
         return at once; pass the result to ``loss_and_grad(batch, sched=...)``.  A data
         loader that calls this one batch ahead hides the schedule's host round trip
-        (its build kernels run beside the previous step when ``resident``)."""
+        (its build kernels run beside the previous step when ``resident``).
+        ``on_side_stream``: queue it on the library's side stream instead of a third stream --
+        call it just BEFORE the current step's ``loss_and_grad``: the side stream idles through the
+        encoder's forward sweep, and a process that also runs RCCL stays within the 4 hardware
+        queues the box gives it."""
         g, x, sizes = _batch_parts(batch)
         dev = g.device
-        if self._prep is None or self._prep.device != dev:
-            self._prep = torch.cuda.Stream(device=dev)
+        if on_side_stream:
+            stream = E.side_stream(dev)
+        else:
+            if self._prep is None or self._prep.device != dev:
+                self._prep = torch.cuda.Stream(device=dev)
+            stream = self._prep
         if not resident:   # resident=True: the batch tensors are complete already, start at once
-            self._prep.wait_stream(torch.cuda.current_stream())
-        return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, stream=self._prep, defer=True, x=x)
+            stream.wait_stream(torch.cuda.current_stream())
+        return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, stream=stream, defer=True, x=x)
 
     def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, sched=None):
         """Forward + backward of training_step's loss without building an autograd
