@@ -20,6 +20,11 @@ CASES = {
     "none_bidir_h501": (None, True, False, 501, 8, 8, 6, 0.4, False),
     "bn_uni_h501": ("bn", False, False, 501, 10, 10, 5, 0.3, False),
     "none_uni_h128_n20": (None, False, False, 128, 20, 6, 5, 0.15, False),
+    # fused pair backward, LDS accumulators (9..16 nodes at add_edge width 1024)
+    "none_uni_h200_n12": (None, False, False, 200, 12, 6, 6, 0.3, False),
+    # fused pair backward, register accumulators at widths 1024 and 3072
+    "none_uni_h200_n8": (None, False, False, 200, 8, 6, 7, 0.4, True),
+    "bn_uni_h501_n8": ("bn", False, False, 501, 8, 8, 5, 0.35, False),
     # source nodes other than node 0 (level 0 holds several nodes of a graph; their k = 0 rows are scored)
     "none_uni_h64_orphans": (None, False, False, 64, 9, 6, 10, 0.25, False, False),
     "none_bidir_h64_orphans": (None, True, False, 64, 8, 5, 7, 0.2, False, False),
