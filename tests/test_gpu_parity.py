@@ -28,6 +28,9 @@ CASES = {
     # degenerate sizes: two nodes (no scored edge row at all), a single node (no edge, no pair)
     "none_uni_h64_n2": (None, False, False, 64, 2, 4, 5, 0.5, False),
     "none_bidir_h64_n1": (None, True, False, 64, 1, 3, 4, 0.5, False),
+    # limits: the maximum number of node types (31: the one-hot tables have 32 columns), batch of one
+    "none_uni_h64_c31": (None, False, False, 64, 6, 31, 9, 0.4, False),
+    "bn_bidir_h64_c31_b1": ("bn", True, False, 64, 7, 31, 1, 0.4, False),
     # source nodes other than node 0 (level 0 holds several nodes of a graph; their k = 0 rows are scored)
     "none_uni_h64_orphans": (None, False, False, 64, 9, 6, 10, 0.25, False, False),
     "none_bidir_h64_orphans": (None, True, False, 64, 8, 5, 7, 0.2, False, False),
