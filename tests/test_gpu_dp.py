@@ -1,0 +1,63 @@
+"""GPU: the data-parallel product path end to end with two processes on ONE card (gloo carries the
+collective; on an 8-GPU node it is RCCL): each rank runs the HIP train step on its contiguous shard,
+the flat gradient buffers are SUM all-reduced while the encoder's backward still runs, and the result
+equals the single-process gradient of the whole batch."""
+import os
+import sys
+from argparse import Namespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dvae_amd
+    from dvae_amd import dp
+    from helpers import fill_weights
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    hp = Namespace(dataset_file=None, mod=None, bidirectional=True, num_classes=6, max_seq=8, hidden_state_size=64)
+    model = fill_weights(dvae_amd.Dvae(hp), 7).to(dev)
+    g, x = dvae_amd.synth.random_dags(11, 8, 6, 0.35, 3, chain=True)           # 11 graphs: shards of 6 and 5
+    eps = torch.randn(11, 56, generator=torch.Generator().manual_seed(0))      # drawn per GLOBAL graph index
+    full = {'graph': g.to(dev), 'node_encoding': x.to(dev)}
+    mine = dp.shard_batch(dict(full, eps=eps.to(dev)), rank, world)
+    sync = dp.make_grad_sync(dist)
+    nxt = model.prepare(mine, resident=True, on_side_stream=True)              # what bench.py does with RCCL in the process
+    out4 = model.loss_and_grad(mine, eps=mine['eps'], grad_sync=sync, sched=nxt)
+    losses = dp.allreduce_losses(dist, out4.clone())
+    torch.cuda.synchronize()
+    grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    if rank == 0:
+        ref4 = model.loss_and_grad(full, eps=eps.to(dev))
+        torch.cuda.synchronize()
+        ref = torch.cat([p.grad.flatten() for p in model.parameters()])
+        ret['grad_rel'] = float((grads - ref).norm() / ref.norm())
+        ret['grad_max'] = float((grads - ref).abs().max() / ref.abs().max())
+        ret['loss_err'] = float((losses - ref4).abs().max() / ref4.abs().max())
+        ret['rows'] = int(mine['graph'].shape[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_the_big_batch():
+    world = 2
+    port = 30500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert ret['rows'] == 6
+        assert ret['loss_err'] < 1e-5, ret['loss_err']
+        assert ret['grad_rel'] < 1e-5 and ret['grad_max'] < 1e-4, dict(ret)
