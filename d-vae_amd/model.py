@@ -368,15 +368,19 @@ class Dvae(nn.Module):
             d_enc = E._dims_for(enc._dims, sched.B, sched.N)
             d_dec = E._dims_for(dec._dims, sched.B, sched.N)
             Pe = enc._pack.pack(d_enc, enc_p)
-            Pd = dec._pack.pack(d_dec, dec_p)
             fe, fd = self._flat_grads()
             side = E.side_stream(main.device)
             side.wait_stream(main)
+            with torch.cuda.stream(side):     # the decoder's weights are not needed before the encoder is through
+                Pd = dec._pack.pack(d_dec, dec_p)
+                pd_ready = torch.cuda.Event()
+                pd_ready.record(side)
             handles = []
             ec = E.EncoderCall(d_enc, sched, xs, Pe)
             if eps is None:
                 eps = torch.randn_like(ec.mu)
             z = E.reparam_fwd(ec.mu, ec.logvar, eps)
+            main.wait_event(pd_ready)
             dc = E.DecoderCall(d_dec, sched, z, xs, Pd, side=side)
             out4, (ge, gt, gmu, glv) = E.elbo_call(d_dec, dc.edge_logits, dc.type_logits, sched.g, xs, sched.sizes,
                                                    ec.mu, ec.logvar, float(beta), True)
