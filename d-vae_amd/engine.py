@@ -337,6 +337,21 @@ def predict_call(dims, z, P, u_type=None, u_edge=None, want_margin=False):
 # ---------------------------------------------------------------------------
 # autograd Functions
 # ---------------------------------------------------------------------------
+def _bwd_on_two_streams(pack, G, run):
+    """A module's backward as the fused step runs it: the level chain on the current stream, every
+    weight-gradient product on the library's side stream, the unpack behind them there; the current
+    stream continues once the side stream is through.  Returns (flat gradients, run's result)."""
+    main = torch.cuda.current_stream()
+    side = side_stream(G.device)
+    side.wait_stream(main)
+    flat = torch.empty(pack.total, dtype=torch.float32, device=G.device)   # owned by `main`'s allocator pool
+    res = run(side)
+    with torch.cuda.stream(side):
+        pack.unpack(G, flat)
+    main.wait_stream(side)
+    return flat, res
+
+
 class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, sched, x, *params):
@@ -351,8 +366,9 @@ class EncoderFn(torch.autograd.Function):
         pack = ctx.module._pack
         G = pack.new_packed_grad()
         cont = lambda t: None if t is None else t.contiguous()
-        ctx.call.backward(cont(d_hv), cont(d_mu), cont(d_logvar), G)
-        grads = pack.views(pack.unpack(G), ctx.params)
+        flat = _bwd_on_two_streams(
+            pack, G, lambda side: ctx.call.backward(cont(d_hv), cont(d_mu), cont(d_logvar), G, side=side))[0]
+        grads = pack.views(flat, ctx.params)
         ctx.call = None
         return (None, None, None) + tuple(grads)
 
@@ -362,7 +378,10 @@ class DecoderFn(torch.autograd.Function):
     def forward(ctx, module, sched, z, x, *params):
         dims = _dims_for(module._dims, sched.B, sched.N)
         P = module._pack.pack(dims, params)
-        call = DecoderCall(dims, sched, _f32c(z), x, P)
+        main = torch.cuda.current_stream()
+        side = side_stream(x.device)       # add_edge's first layer and add_vertex run beside the level chain;
+        side.wait_stream(main)             # the library orders the side stream back into `main` before it returns
+        call = DecoderCall(dims, sched, _f32c(z), x, P, side=side)
         ctx.call, ctx.module, ctx.params = call, module, params
         ctx.need_dz = z.requires_grad
         return call.edge_logits, call.type_logits
@@ -371,8 +390,9 @@ class DecoderFn(torch.autograd.Function):
     def backward(ctx, d_edge, d_type):
         pack = ctx.module._pack
         G = pack.new_packed_grad()
-        d_z = ctx.call.backward(d_edge.contiguous(), d_type.contiguous(), G, want_dz=True)
-        grads = pack.views(pack.unpack(G), ctx.params)
+        flat, d_z = _bwd_on_two_streams(
+            pack, G, lambda side: ctx.call.backward(d_edge.contiguous(), d_type.contiguous(), G, want_dz=True, side=side))
+        grads = pack.views(flat, ctx.params)
         ctx.call = None
         return (None, None, d_z, None) + tuple(grads)
 
