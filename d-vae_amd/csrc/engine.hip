@@ -20,6 +20,7 @@ namespace {
 
 struct LevelCfg {
   int fused_gm_min_rows; int fused_gru; int type_share;
+  int node_hidden = getenv("DVAE_NO_NODE_HIDDEN") ? 0 : 1;   // prefix sweeps: one hidden product per node (SweepBufs::PG)
   LevelCfg() {
     type_share = getenv("DVAE_NO_TYPE_SHARE") ? 0 : 1;
     fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : getenv("DVAE_FUSED_GM_MIN") ? atoi(getenv("DVAE_FUSED_GM_MIN")) : 2048;
@@ -63,10 +64,13 @@ void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP, int 
     s.HV = c.f(rh * HP);
     s.Hn = c.f(r * HP);
     s.DHn = c.f(r * HP);
+    s.PG = c.f(r * 3 * HP);
+    s.DGM = c.f(r * HP);
   } else {
     s.Hn = c.f(r * HP);
     s.HV = s.Hn;
     s.DHn = nullptr;
+    s.PG = s.DGM = nullptr;
   }
 }
 
@@ -278,6 +282,11 @@ bool scored_rows_only() {
 }
 bool skip_level0(const int* info) { return scored_rows_only() && info[7] == 1; }
 
+// prefix sweeps in mod None sum the GRU's hidden product from one product per node (kernels.h SweepBufs::PG)
+bool node_hidden(const dvae_dims& d, const SweepBufs& b) {
+  return g_level_cfg.node_hidden && b.prefix && d.mod == 0 && !g_level_cfg.fused_gru;
+}
+
 struct SweepW {
   GruW gru; const float* gm;   // gm: Wgm|posb (None) or WgmT|bgm (bn)
 };
@@ -329,16 +338,18 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     DVAE_TRY(k_gru_fwd(S, z1, R, 1, b, x, d.N, d.C, w.gru, HP, st));
     if (hook) DVAE_TRY(hook(z1, R, 0, 0));
   }
+  const bool pg = node_hidden(d, b);
   for (int L = 0; L < lv.nlev; ++L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
     int p0 = ns, p1 = ne;
-    DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st));
+    DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st, pg ? 1 : 0));
     if (L == 0) {
       if (h0) DVAE_TRY(gru_rows(ns, ne));
       else DVAE_TRY(k_gru_fwd(S, ns, ne, 1, b, x, d.N, d.C, w.gru, HP, st));
     } else {
       if (b.prefix) { p0 = R + lv.es[L]; p1 = R + lv.es[L + 1]; }
-      DVAE_TRY(gru_rows(p0, p1));
+      if (pg) DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));   // GH rows summed by k_agg_fwd
+      else DVAE_TRY(gru_rows(p0, p1));
     }
     if (hook) DVAE_TRY(hook(p0, p1, ns, ne));
     if (L + 1 < lv.nlev) {   // nodes of the last level have no successors
@@ -349,6 +360,9 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
                       HP));
         DVAE_TRY(k_gm_fwd(S, ns, ne, b, w.gm + (size_t)2 * HP * HP, HP, st));
       }
+      // the hidden product of this level's gated states, once per node
+      if (pg)
+        DVAE_TRY(g.nt(b.GM + (size_t)ns * HP, HP, w.gru.Whh, HP, b.PG + (size_t)ns * 3 * HP, 3 * HP, ne - ns, 3 * HP, HP));
     }
   }
   return DVAE_OK;
@@ -382,10 +396,20 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     return DVAE_OK;
   }
   float* dtarget = b.prefix ? b.DHn : b.DH;
+  const bool pg = node_hidden(d, b);
   for (int L = lv.nlev - 1; L >= 0; --L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
     if (L + 1 < lv.nlev) {
-      DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
+      if (pg) {
+        // dL/dGM[u] = (direct gradients of the rows that hold u) + (their dgh, summed).Whh: the hidden
+        // product's input gradient once per node instead of once per prefix row
+        DVAE_TRY(k_dgm_gather(S, ns, ne, b, HP, st));
+        DVAE_TRY(g.nn(b.PG + (size_t)ns * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DGM + (size_t)ns * HP, HP, ne - ns, HP,
+                      3 * HP, 1));
+        DVAE_TRY(k_gm_bwd_apply(ns, ne, b, HP, st));
+      } else {
+        DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
+      }
       DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
                     2 * HP, 1));
     }
@@ -395,7 +419,7 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     } else {
       const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
       DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
-      DVAE_TRY(dagg_gemm(p0, p1));
+      if (!pg) DVAE_TRY(dagg_gemm(p0, p1));
     }
     if (after_level) DVAE_TRY(after_level(L));   // levels >= L are final from here on
   }
@@ -441,7 +465,13 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
     DVAE_TRY(gru_rows(n0, n1, acc));
   } else {
     const int e0 = R > 0 ? R + lv.es[La] : 0, e1 = R > 0 ? R + lv.es[Lb] : 0;   // edge rows of the chunk
-    DVAE_TRY(g.tn(b.GH + (size_t)e0 * 3 * HP, 3 * HP, b.AGG + (size_t)e0 * HP, HP, o.Ggru, HP, 3 * HP, HP, e1 - e0, acc));
+    if (node_hidden(d, b)) {
+      // dWhh = sum over nodes of (dgh summed over the rows that hold the node)^T . GM[node]
+      const int r1 = std::min(n1, Rg);
+      DVAE_TRY(g.tn(b.PG + (size_t)n0 * 3 * HP, 3 * HP, b.GM + (size_t)n0 * HP, HP, o.Ggru, HP, 3 * HP, HP, r1 - n0, acc));
+    } else {
+      DVAE_TRY(g.tn(b.GH + (size_t)e0 * 3 * HP, 3 * HP, b.AGG + (size_t)e0 * HP, HP, o.Ggru, HP, 3 * HP, HP, e1 - e0, acc));
+    }
     DVAE_TRY(gru_rows(e0, e1, acc));
     if (low) {
       if (seeded && z1 > 0) DVAE_TRY(g.tn(b.GH, 3 * HP, b.AGG, HP, o.Ggru, HP, 3 * HP, HP, z1, 1));

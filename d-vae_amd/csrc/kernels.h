@@ -37,9 +37,20 @@ struct SweepBufs {
   float* DHn;       // [R][HP]   prefix only: extra gradient of the final states
   float* XP;        // [RH][32]  node encoding | 1 of every row (weight-gradient GEMMs)
   float* PX;        // [R][PP]   None: position one-hot | 1; bn: node encoding | 1 per node
+  // prefix sweeps, mod None ("hidden product per node"): the GRU's hidden product of a prefix row is
+  // linear in its h_in = sum of the predecessors' gated states, so it is summed from ONE product per
+  // node, PG[u] = Whh.GM[u], instead of being computed per prefix row (E + N rows -> N rows)
+  float* PG;        // [R][3HP]  Whh.GM[u] -> after the backward gather: dL/dPG[u] = sum of dgh over the rows that hold u
+  float* DGM;       // [R][HP]   backward: dL/dGM[u] (direct part gathered, hidden part added by a GEMM)
 };
 
-int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st);
+// with_pg (prefix sweeps): also sums the nodes' hidden products PG into the GH rows of the prefix rows
+int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st,
+              int with_pg = 0);
+// prefix sweeps with PG: DGM[u] = sum of DH over the consumer rows that hold u, PG[u] = the same sum of dgh (GH)
+int k_dgm_gather(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
+// ... and, once DGM is complete, through g*m:  GMP <- (dGM*m*g*(1-g), dGM*g)
+int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, const float* x, int N, int C,
               const GruW& w, int HP, hipStream_t st);
 int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st);

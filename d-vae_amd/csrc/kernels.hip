@@ -39,14 +39,34 @@ __device__ __forceinline__ float wave_sum(float v) {
 // prefix mode writes every running sum (decoder suffix states, :223-241).
 // ---------------------------------------------------------------------------
 __global__ void agg_fwd_kernel(SchedDir S, int R, int ns, int ne, int prefix, const float* __restrict__ GM,
-                               float* __restrict__ AGG, const float* __restrict__ h0, int HP) {
+                               float* __restrict__ AGG, const float* __restrict__ h0, int HP,
+                               const float* __restrict__ PG, float* __restrict__ GH) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(ne - ns) * HP4;
   ITEM_LOOP(total) {
     const int r = ns + (int)(it / HP4), q = (int)(it % HP4);
     const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
     float4 acc = zero4();
-    if (!prefix) {
+    if (prefix && PG) {
+      // running sums of the gated states AND of their hidden products (three gate columns each)
+      if (h0 && S.row_node[r] == 0) acc = ld4(h0 + (size_t)S.row_graph[r] * HP + q * 4);
+      st4(AGG + (size_t)r * HP + q * 4, acc);
+      float4 g0 = zero4(), g1 = zero4(), g2 = zero4();
+      for (int t = 0; t < deg; ++t) {
+        const size_t u = S.csr_idx[p + t];
+        acc = add4(acc, ld4(GM + u * HP + q * 4));
+        const float* pu = PG + u * 3 * HP + q * 4;
+        g0 = add4(g0, ld4(pu));
+        g1 = add4(g1, ld4(pu + HP));
+        g2 = add4(g2, ld4(pu + 2 * HP));
+        const size_t row = (size_t)R + p + t;
+        st4(AGG + row * HP + q * 4, acc);
+        float* gh = GH + row * 3 * HP + q * 4;
+        st4(gh, g0);
+        st4(gh + HP, g1);
+        st4(gh + 2 * HP, g2);
+      }
+    } else if (!prefix) {
       for (int t = 0; t < deg; ++t) acc = add4(acc, ld4(GM + (size_t)S.csr_idx[p + t] * HP + q * 4));
       st4(AGG + (size_t)r * HP + q * 4, acc);
     } else {
@@ -249,6 +269,51 @@ __global__ void dgm_bwd_kernel(SchedDir S, int ns, int ne, int prefix, const flo
         d = add4(d, ld4(DAGG + (size_t)S.csc_idx[e] * HP + j));
       }
     }
+    float* gp = GMP + (size_t)r * 2 * HP;
+    const float4 g = ld4(gp + j), m = ld4(gp + HP + j);
+    st4(gp + j, make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
+                            d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w)));
+    st4(gp + HP + j, make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w));
+  }
+}
+
+// Prefix sweeps with one hidden product per node: for node u, over every consumer prefix row that
+// holds u, DGM[u] = sum of the direct gradients (DH after gru_bwd) and PG[u] = sum of dgh (GH after
+// gru_bwd).  dL/dGM[u] = DGM[u] + PG[u].Whh follows by a GEMM, then gm_bwd_apply.
+__global__ void dgm_gather_kernel(SchedDir S, int ns, int ne, const float* __restrict__ DAGG,
+                                  const float* __restrict__ GH, float* __restrict__ DGM, float* __restrict__ PG,
+                                  int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(ne - ns) * HP4;
+  ITEM_LOOP(total) {
+    const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    float4 d = zero4(), g0 = zero4(), g1 = zero4(), g2 = zero4();
+    const int e0 = S.csc_ptr[r], e1 = S.csc_ptr[r + 1];
+    for (int e = e0; e < e1; ++e) {
+      const size_t pr = S.csc_prow[e];
+      const int cnt = S.csc_cnt[e];
+      for (int t = 0; t < cnt; ++t) {
+        d = add4(d, ld4(DAGG + (pr + t) * HP + j));
+        const float* gh = GH + (pr + t) * 3 * HP + j;
+        g0 = add4(g0, ld4(gh));
+        g1 = add4(g1, ld4(gh + HP));
+        g2 = add4(g2, ld4(gh + 2 * HP));
+      }
+    }
+    st4(DGM + (size_t)r * HP + j, d);
+    float* pg = PG + (size_t)r * 3 * HP + j;
+    st4(pg, g0);
+    st4(pg + HP, g1);
+    st4(pg + 2 * HP, g2);
+  }
+}
+
+__global__ void gm_bwd_apply_kernel(int ns, int ne, const float* __restrict__ DGM, float* __restrict__ GMP, int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(ne - ns) * HP4;
+  ITEM_LOOP(total) {
+    const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const float4 d = ld4(DGM + (size_t)r * HP + j);
     float* gp = GMP + (size_t)r * 2 * HP;
     const float4 g = ld4(gp + j), m = ld4(gp + HP + j);
     st4(gp + j, make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
@@ -995,10 +1060,27 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
 // ===========================================================================
 // launchers
 // ===========================================================================
-int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st) {
+int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st,
+              int with_pg) {
   if (ne <= ns) return DVAE_OK;
   hipLaunchKernelGGL(agg_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns, ne,
-                     b.prefix, b.GM, b.AGG, h0, HP);
+                     b.prefix, b.GM, b.AGG, h0, HP, with_pg ? b.PG : nullptr, b.GH);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_dgm_gather(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  hipLaunchKernelGGL(dgm_gather_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, ns, ne, b.DH,
+                     b.GH, b.DGM, b.PG, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  hipLaunchKernelGGL(gm_bwd_apply_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, ns, ne, b.DGM,
+                     b.GMP, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
