@@ -342,13 +342,15 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   for (int L = 0; L < lv.nlev; ++L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
     int p0 = ns, p1 = ne;
-    DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st, pg ? 1 : 0));
+    static const bool split_pg = getenv("DVAE_PG_SPLIT") != nullptr;   // lab: aggregation and gates as two launches
+    if (!(pg && L > 0 && !split_pg)) DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st, pg ? 1 : 0));
     if (L == 0) {
       if (h0) DVAE_TRY(gru_rows(ns, ne));
       else DVAE_TRY(k_gru_fwd(S, ns, ne, 1, b, x, d.N, d.C, w.gru, HP, st));
     } else {
       if (b.prefix) { p0 = R + lv.es[L]; p1 = R + lv.es[L + 1]; }
-      if (pg) DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));   // GH rows summed by k_agg_fwd
+      if (pg && !split_pg) DVAE_TRY(k_prefix_gru_fwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, st));   // aggregation + gates
+      else if (pg) DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));              // GH rows summed by k_agg_fwd
       else DVAE_TRY(gru_rows(p0, p1));
     }
     if (hook) DVAE_TRY(hook(p0, p1, ns, ne));

@@ -47,6 +47,10 @@ struct SweepBufs {
 // with_pg (prefix sweeps): also sums the nodes' hidden products PG into the GH rows of the prefix rows
 int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* h0, int HP, hipStream_t st,
               int with_pg = 0);
+// prefix sweeps with PG, levels >= 1: aggregation (running h_in and running Whh.h_in from PG) and the
+// GRUCell epilogue of every edge prefix row of node rows [ns,ne) in one pass
+int k_prefix_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
+                     const GruW& w, int HP, hipStream_t st);
 // prefix sweeps with PG: DGM[u] = sum of DH over the consumer rows that hold u, PG[u] = the same sum of dgh (GH)
 int k_dgm_gather(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 // ... and, once DGM is complete, through g*m:  GMP <- (dGM*m*g*(1-g), dGM*g)

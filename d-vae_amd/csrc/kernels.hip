@@ -133,6 +133,65 @@ __global__ void gru_fwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, in
   }
 }
 
+// Prefix sweeps with one hidden product per node (SweepBufs::PG): aggregation and GRUCell epilogue of
+// every edge prefix row of node rows [ns, ne) in one pass.  Row k of a node adds predecessor k's gated
+// state to the running h_in and its hidden product PG to the running W_hh.h_in, then applies the
+// gates; the input part W_ih.x + b_ih is the node's and is computed once.  Nothing of the running
+// sums goes through memory except the h_in rows the backward pass reads (AGG).
+__global__ void prefix_gru_fwd_kernel(SchedDir S, int R, int ns, int ne, const float* __restrict__ GM,
+                                      const float* __restrict__ PG, float* __restrict__ AGG,
+                                      float* __restrict__ GH, float* __restrict__ GHN, float* __restrict__ HV,
+                                      float* __restrict__ Hn, const float* __restrict__ x, int N, int C, GruW w,
+                                      int HP) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(ne - ns) * HP4;
+  ITEM_LOOP(total) {
+    const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+    st4(AGG + (size_t)r * HP + j, zero4());     // the node's own (k = 0) row: h_in = 0 at levels >= 1
+    if (deg == 0) continue;
+    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
+    float4 gi[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gi[g] = ld4(w.bih + g * HP + j);
+    for (int c = 0; c < C; ++c) {
+      const float xv = xr[c];
+      if (xv != 0.f) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gi[g] = fma4(xv, ld4(w.WihT + (size_t)c * 3 * HP + g * HP + j), gi[g]);
+      }
+    }
+    const float4 br = ld4(w.bhh + j), bz = ld4(w.bhh + HP + j), bn = ld4(w.bhh + 2 * HP + j);
+    float4 a = zero4(), g0 = zero4(), g1 = zero4(), g2 = zero4();
+    for (int t = 0; t < deg; ++t) {
+      const size_t u = S.csr_idx[p + t];
+      a = add4(a, ld4(GM + u * HP + j));
+      const float* pu = PG + u * 3 * HP + j;
+      g0 = add4(g0, ld4(pu));
+      g1 = add4(g1, ld4(pu + HP));
+      g2 = add4(g2, ld4(pu + 2 * HP));
+      const float4 ghr = add4(br, g0), ghz = add4(bz, g1), ghn = add4(bn, g2);
+      float4 rr, zz, nn, hh;
+#define PG_LANE(f)                                    \
+      rr.f = sigm(gi[0].f + ghr.f);                     \
+      zz.f = sigm(gi[1].f + ghz.f);                     \
+      nn.f = tanhf(gi[2].f + rr.f * ghn.f);             \
+      hh.f = (1.f - zz.f) * nn.f + zz.f * a.f;
+      PG_LANE(x) PG_LANE(y) PG_LANE(z) PG_LANE(w)
+#undef PG_LANE
+      const size_t row = (size_t)R + p + t;
+      st4(AGG + row * HP + j, a);
+      float* gh = GH + row * 3 * HP + j;
+      st4(gh, rr);
+      st4(gh + HP, zz);
+      st4(gh + 2 * HP, nn);
+      st4(GHN + row * HP + j, ghn);
+      st4(HV + row * HP + j, hh);
+      if (t == deg - 1) st4(Hn + (size_t)r * HP + j, hh);
+    }
+  }
+}
+
 // GRU state of a node of type c whose h_in is 0: TYPEV[c] for c < C, zero rows up to 32.
 // Same arithmetic as gru_fwd_kernel's no_gh path on a one-hot encoding.
 __global__ void type_states_kernel(int C, GruW w, float* __restrict__ TYPEV, int HP) {
@@ -1065,6 +1124,15 @@ int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float
   if (ne <= ns) return DVAE_OK;
   hipLaunchKernelGGL(agg_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns, ne,
                      b.prefix, b.GM, b.AGG, h0, HP, with_pg ? b.PG : nullptr, b.GH);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_prefix_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
+                     const GruW& w, int HP, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  hipLaunchKernelGGL(prefix_gru_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns,
+                     ne, b.GM, b.PG, b.AGG, b.GH, b.GHN, b.HV, b.Hn, x, N, C, w, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
