@@ -509,11 +509,14 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   // next smaller tile wins), and between 128x128 and 64x128 the one that needs fewer
   // "rounds" of 256 CUs.  Long reductions into a small output keep 128x128 and split K.
   const bool narrow = d.N <= 32;
+  // at most 32 output rows (add_vertex.2's weight gradient: 32 x 1024 summed over all node rows;
+  // the per-type tables): a 32x128 tile instead of wasting three quarters of a 128-row one
+  const bool flat = !narrow && d.M <= 32 && !d.k_map && !d.row_map && g_force_tile == 0;
   bool half = false, quarter = false;
   if (g_force_tile == 1) half = false;
   else if (g_force_tile == 2) half = true;
   else if (g_force_tile == 3) quarter = true;
-  else if (!narrow) {
+  else if (!narrow && !flat) {
     const long long t128 = (long long)cdiv(d.M, 128) * cdiv(d.N, 128);
     const long long t64 = (long long)cdiv(d.M, 64) * cdiv(d.N, 128);
     const bool splitk = d.K >= 8192 && t128 < 256 && ws;   // weight gradients: reduction over all rows
@@ -526,6 +529,7 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   }
 #define GEMM_PICK(AK, BKK)                                                                   \
   if (narrow) return launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream);                \
+  if (flat) return launch<AK, BKK, 32, 128, 1, 4>(d, ws, ws_bytes, stream);                  \
   if (quarter) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);                \
   if (g_variant == 3)                                                                        \
     return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 1>(d, ws, ws_bytes, stream)             \

@@ -98,7 +98,7 @@ def test_gemm_asymmetric_exact(cuda):
     assert torch.equal(out, W.t().contiguous())
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 512, 1536), (777, 512, 1024), (64, 1024, 32), (130, 512, 2048)])
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 1536), (777, 512, 1024), (64, 1024, 32), (130, 512, 2048), (24, 512, 1024), (32, 2048, 512)])
 def test_gemm_nn(cuda, M, N, K):
     from dvae_amd._lib import load
     lib = load()
