@@ -180,7 +180,7 @@ def test_predict_parity(cuda, mod):
     assert int(same.sum()) >= M - 2, "stochastic decode differs on %d/%d graphs" % (M - int(same.sum()), M)
 
 
-@pytest.mark.parametrize("seed", list(range(14)))
+@pytest.mark.parametrize("seed", list(range(40)))
 def test_random_configurations_against_oracle(cuda, seed):
     """Seeded random model / graph configurations (sizes, widths, modes, densities, orphan sources):
     the four losses and every parameter gradient against the oracle."""
