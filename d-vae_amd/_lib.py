@@ -25,6 +25,11 @@ class DvaeDims(ctypes.Structure):
         "HP", "ZP", "EH", "EHP", "VHP", "CP")]
 
 
+class SvaeDims(ctypes.Structure):
+    """Mirror of ``struct dvae_svae_dims``."""
+    _fields_ = [(n, c_int) for n in ("B", "T", "C", "N", "H", "Z", "bidir", "I", "IP", "HP", "ZP")]
+
+
 class PackEntry(ctypes.Structure):
     """Mirror of ``struct dvae_pack_entry``."""
     _fields_ = [("raw", ctypes.c_uint64), ("grad", ctypes.c_int64),
@@ -89,6 +94,21 @@ SIGNATURES = {
     "dvae_elbo": (c_int, [_P(DvaeDims)] + [c_void_p] * 7 + [c_float] + [c_void_p] * 7),
     "dvae_predict_ws_bytes": (c_size_t, [_P(DvaeDims)]),
     "dvae_decoder_predict": (c_int, [_P(DvaeDims)] + [c_void_p] * 9),
+    "dvae_svae_dims_init": (c_int, [_P(SvaeDims)]),
+    "dvae_svae_enc_param_floats": (c_size_t, [_P(SvaeDims)]),
+    "dvae_svae_dec_param_floats": (c_size_t, [_P(SvaeDims)]),
+    "dvae_svae_enc_param_count": (c_int, [_P(SvaeDims)]),
+    "dvae_svae_dec_param_count": (c_int, [_P(SvaeDims)]),
+    "dvae_svae_enc_pack_table": (c_int, [_P(SvaeDims), c_void_p, c_void_p, c_void_p, c_int]),
+    "dvae_svae_dec_pack_table": (c_int, [_P(SvaeDims), c_void_p, c_void_p, c_void_p, c_int]),
+    "dvae_svae_enc_ws_bytes": (c_size_t, [_P(SvaeDims)]),
+    "dvae_svae_dec_ws_bytes": (c_size_t, [_P(SvaeDims)]),
+    "dvae_svae_enc_fwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 6),
+    "dvae_svae_enc_bwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 6),
+    "dvae_svae_dec_fwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 6),
+    "dvae_svae_dec_bwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 7),
+    "dvae_svae_elbo": (c_int, [_P(SvaeDims)] + [c_void_p] * 5 + [c_float] + [c_void_p] * 7),
+    "dvae_svae_predict": (c_int, [_P(SvaeDims), c_ll] + [c_void_p] * 7),
     "dvae_side_stream_create": (c_int, [_P(c_void_p), _P(c_int)]),
     "dvae_side_stream_destroy": (c_int, [c_void_p]),
 }
@@ -130,6 +150,13 @@ def make_dims(B, N, C, H, Z, mod, bidir, npos):
     d.bidir = int(bool(bidir))
     d.npos = int(npos) if mod is None else 0
     check(load().dvae_dims_init(ctypes.byref(d)))
+    return d
+
+
+def make_svae_dims(B, T, C, N, H, Z, bidir):
+    d = SvaeDims()
+    d.B, d.T, d.C, d.N, d.H, d.Z, d.bidir = int(B), int(T), int(C), int(N), int(H), int(Z), int(bool(bidir))
+    check(load().dvae_svae_dims_init(ctypes.byref(d)))
     return d
 
 

@@ -4,6 +4,7 @@
 #include <stdio.h>
 
 #include "layout.h"
+#include "svae_layout.h"
 
 static thread_local char g_err[512] = "";
 void dvae_set_error(const char* fmt, ...) {
@@ -111,6 +112,16 @@ struct TableBuilder {
       add_g(mb, 0, H, 1, 1, 0, xm + C, 32);
     }
   }
+  // S-VAE sequence GRU (nn.GRU layout: gates r|z|n stacked on rows; K = raw input width)
+  void seq_gru(const dvae_svae_dims& d, const SvaeGru& w, int K, int KP, int wih, int whh, int bih, int bhh) {
+    const int H = d.H, HP = d.HP;
+    for (int g = 0; g < 3; ++g) {
+      add(0, wih, (size_t)g * H * K, H, K, K, 0, w.Wih + (size_t)g * HP * KP, KP);
+      add(0, whh, (size_t)g * H * H, H, H, H, 0, w.Whh + (size_t)g * HP * HP, HP);
+      add(0, bih, (size_t)g * H, 1, H, H, 0, w.bih + (size_t)g * HP, HP);
+      add(0, bhh, (size_t)g * H, 1, H, H, 0, w.bhh + (size_t)g * HP, HP);
+    }
+  }
 };
 
 __global__ void pack_kernel(const dvae_pack_entry* __restrict__ table, float* __restrict__ P) {
@@ -214,6 +225,68 @@ extern "C" int dvae_dec_pack_table(const dvae_dims* dp, const uint64_t* raw, con
   tb.add(0, 8, 0, 1, d.EH, d.EH, 0, L.w2, d.EHP);
   tb.add(0, 9, 0, 1, 1, 1, 0, L.b2, 4);
   DVAE_REQUIRE(!tb.overflow, "dec_pack_table: table too small");
+  return tb.n;
+}
+
+// ---- S-VAE baseline (svae_model.py:13-79) ---------------------------------------
+extern "C" int dvae_svae_dims_init(dvae_svae_dims* d) {
+  DVAE_REQUIRE(d, "svae dims: null");
+  DVAE_REQUIRE(d->B > 0 && d->T > 0 && d->T <= 1024, "svae dims: B and T must be positive (T <= 1024)");
+  DVAE_REQUIRE(d->C > 0 && d->C <= 32 && d->N > 0 && d->N <= 32, "svae dims: node_type and max_seq_len must be in [1,32]");
+  DVAE_REQUIRE(d->H > 0 && d->H <= 2048 && d->Z > 0 && d->Z <= 1024, "svae dims: H/Z out of range");
+  d->I = d->C + d->N;
+  d->IP = round_up(d->I, 32);
+  d->HP = round_up(d->H, 64);
+  d->ZP = round_up(d->Z, 64);
+  return DVAE_OK;
+}
+extern "C" size_t dvae_svae_enc_param_floats(const dvae_svae_dims* d) { return svae_enc_layout(*d).total; }
+extern "C" size_t dvae_svae_dec_param_floats(const dvae_svae_dims* d) { return svae_dec_layout(*d).total; }
+extern "C" int dvae_svae_enc_param_count(const dvae_svae_dims* d) { return d->bidir ? 14 : 8; }
+extern "C" int dvae_svae_dec_param_count(const dvae_svae_dims*) { return 14; }
+
+extern "C" int dvae_svae_enc_pack_table(const dvae_svae_dims* dp, const uint64_t* raw, const int64_t* grad,
+                                        dvae_pack_entry* table, int max_entries) {
+  const dvae_svae_dims& d = *dp;
+  const SvaeEncLayout L = svae_enc_layout(d);
+  TableBuilder tb{table, 0, max_entries, false, raw, grad};
+  // canonical order: 0-3 gru_layer.{weight_ih,weight_hh,bias_ih,bias_hh}_l0  4 fc_mu.weight 5 fc_mu.bias
+  // 6 fc_var.weight 7 fc_var.bias | bidir: 8-11 gru_layer.*_l0_reverse  12 hg_unify.weight 13 hg_unify.bias
+  tb.seq_gru(d, L.gru[0], d.I, d.IP, 0, 1, 2, 3);
+  tb.add(0, 4, 0, d.Z, d.H, d.H, 0, L.Wml, d.HP);
+  tb.add(0, 6, 0, d.Z, d.H, d.H, 0, L.Wml + (size_t)d.ZP * d.HP, d.HP);
+  tb.add(0, 5, 0, 1, d.Z, d.Z, 0, L.bml, d.ZP);
+  tb.add(0, 7, 0, 1, d.Z, d.Z, 0, L.bml + d.ZP, d.ZP);
+  if (d.bidir) {
+    tb.seq_gru(d, L.gru[1], d.I, d.IP, 8, 9, 10, 11);
+    tb.add(0, 12, 0, d.H, d.H, 2 * d.H, 0, L.Wun, 2 * d.HP);
+    tb.add(0, 12, 0, d.H, d.H, 2 * d.H, d.H, L.Wun + d.HP, 2 * d.HP);
+    tb.add(0, 13, 0, 1, d.H, d.H, 0, L.bun, d.HP);
+  }
+  DVAE_REQUIRE(!tb.overflow, "svae_enc_pack_table: table too small");
+  return tb.n;
+}
+
+extern "C" int dvae_svae_dec_pack_table(const dvae_svae_dims* dp, const uint64_t* raw, const int64_t* grad,
+                                        dvae_pack_entry* table, int max_entries) {
+  const dvae_svae_dims& d = *dp;
+  const SvaeDecLayout L = svae_dec_layout(d);
+  TableBuilder tb{table, 0, max_entries, false, raw, grad};
+  // canonical order: 0-3 gru_layer.{weight_ih,weight_hh,bias_ih,bias_hh}_l0  4 fc_h0.weight 5 fc_h0.bias
+  // 6 add_vertex.0.weight 7 add_vertex.0.bias 8 add_vertex.2.weight 9 add_vertex.2.bias
+  // 10 add_edges.0.weight 11 add_edges.0.bias 12 add_edges.2.weight 13 add_edges.2.bias
+  tb.seq_gru(d, L.gru, d.H, d.HP, 0, 1, 2, 3);
+  tb.add(0, 4, 0, d.H, d.Z, d.Z, 0, L.Wh0, d.ZP);
+  tb.add(0, 5, 0, 1, d.H, d.H, 0, L.bh0, d.HP);
+  tb.add(0, 6, 0, d.H, d.H, d.H, 0, L.W1, d.HP);
+  tb.add(0, 10, 0, d.H, d.H, d.H, 0, L.W1 + (size_t)d.HP * d.HP, d.HP);
+  tb.add(0, 7, 0, 1, d.H, d.H, 0, L.b1, d.HP);
+  tb.add(0, 11, 0, 1, d.H, d.H, 0, L.b1 + d.HP, d.HP);
+  tb.add(0, 8, 0, d.C, d.H, d.H, 0, L.Wv2, d.HP);
+  tb.add(0, 9, 0, 1, d.C, d.C, 0, L.bv2, 32);
+  tb.add(0, 12, 0, d.N, d.H, d.H, 0, L.We2, d.HP);
+  tb.add(0, 13, 0, 1, d.N, d.N, 0, L.be2, 32);
+  DVAE_REQUIRE(!tb.overflow, "svae_dec_pack_table: table too small");
   return tb.n;
 }
 

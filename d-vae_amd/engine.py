@@ -174,8 +174,16 @@ class ParamPack:
     """Zero-padded device copy of one module's parameters + the table that maps
     reference-shaped tensors to it (and packed gradients back)."""
 
+    # kind -> C entry points (parameter count, pack table, packed floats, packed gradient floats)
+    _FNS = {"enc": ("dvae_enc_param_count", "dvae_enc_pack_table", "dvae_enc_param_floats", "dvae_enc_grad_floats"),
+            "dec": ("dvae_dec_param_count", "dvae_dec_pack_table", "dvae_dec_param_floats", "dvae_dec_grad_floats"),
+            "svae_enc": ("dvae_svae_enc_param_count", "dvae_svae_enc_pack_table", "dvae_svae_enc_param_floats",
+                         "dvae_svae_enc_param_floats"),
+            "svae_dec": ("dvae_svae_dec_param_count", "dvae_svae_dec_pack_table", "dvae_svae_dec_param_floats",
+                         "dvae_svae_dec_param_floats")}
+
     def __init__(self, kind):
-        assert kind in ("enc", "dec")
+        assert kind in self._FNS
         self.kind = kind
         self.key = None
         self.table = None
@@ -186,7 +194,8 @@ class ParamPack:
 
     def _build(self, dims, params):
         lib = load()
-        count = (lib.dvae_enc_param_count if self.kind == "enc" else lib.dvae_dec_param_count)(ctypes.byref(dims))
+        f_count, f_table, f_floats, f_gfloats = (getattr(lib, n) for n in self._FNS[self.kind])
+        count = f_count(ctypes.byref(dims))
         assert len(params) == count, "expected %d parameters, got %d" % (count, len(params))
         raw = np.array([p.data_ptr() for p in params], dtype=np.uint64)
         offs, o = [], 0
@@ -196,8 +205,7 @@ class ParamPack:
         self.offsets, self.total = offs, o
         goff = np.array(offs, dtype=np.int64)
         host = (_lib.PackEntry * 256)()
-        fn = lib.dvae_enc_pack_table if self.kind == "enc" else lib.dvae_dec_pack_table
-        n = fn(ctypes.byref(dims), ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(goff.ctypes.data),
+        n = f_table(ctypes.byref(dims), ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(goff.ctypes.data),
                ctypes.cast(host, ctypes.c_void_p), 256)
         if n < 0:
             check(n)
@@ -205,17 +213,16 @@ class ParamPack:
         dev = params[0].device
         blob = np.frombuffer(bytes(host), dtype=np.uint8)[: n * ctypes.sizeof(_lib.PackEntry)].copy()
         self.table = torch.from_numpy(blob).to(dev)
-        nfl = (lib.dvae_enc_param_floats if self.kind == "enc" else lib.dvae_dec_param_floats)(ctypes.byref(dims))
-        self.nfloats = int(nfl)
-        gfl = (lib.dvae_enc_grad_floats if self.kind == "enc" else lib.dvae_dec_grad_floats)(ctypes.byref(dims))
-        self.gfloats = int(gfl)
+        self.nfloats = int(f_floats(ctypes.byref(dims)))
+        self.gfloats = int(f_gfloats(ctypes.byref(dims)))
         self.P = torch.zeros(self.nfloats, dtype=torch.float32, device=dev)
 
     def pack(self, dims, params):
         for p in params:
             _require_cuda(p, "parameter")
             assert p.dtype == torch.float32 and p.is_contiguous(), "parameters must be contiguous fp32"
-        key = (dims.H, dims.Z, dims.C, dims.N, dims.mod, dims.bidir, dims.npos) + tuple(p.data_ptr() for p in params)
+        shape = tuple(getattr(dims, f) for f, _ in dims._fields_ if f not in ("B", "T"))   # batch-independent fields
+        key = shape + tuple(p.data_ptr() for p in params)
         if key != self.key:
             self._build(dims, params)
             self.key = key

@@ -272,6 +272,75 @@ int dvae_decoder_predict(const dvae_dims* d, const float* z, const float* P, voi
                          const float* u_type, const float* u_edge, float* edges, float* onehot,
                          float* min_margin, void* stream);
 
+/* ------------------------------------------------------------------------
+ * S-VAE baseline (dvae/models/svae_model.py:13-301): the comparison
+ * model of the reference's experiments on the same boundary.  A structure is a string of
+ * T = max_seq_len - 1 rows [one-hot type | parent flags] (dataloader.py:96-103); the
+ * encoder is a (bi)directional GRU over it, the decoder a GRU fed relu(fc_h0 z) at
+ * every step with two MLP heads.  Tables are time-major inside the library (one step's
+ * rows contiguous), the arguments keep the reference's batch-first layouts.
+ * ---------------------------------------------------------------------- */
+typedef struct dvae_svae_dims {
+  int B;      /* strings in the batch                                          */
+  int T;      /* steps = max_seq_len - 1 (svae_model.py:75)                    */
+  int C;      /* node_type  (svae_model.py:15)                                 */
+  int N;      /* max_seq_len: parent-flag columns (svae_model.py:22)           */
+  int H;      /* hidden_size (501)                                             */
+  int Z;      /* latent_dim (56)                                               */
+  int bidir;  /* bidirectional encoder GRU + hg_unify (svae_model.py:24-33)    */
+  /* derived */
+  int I;      /* C + N: input width of the encoder GRU                         */
+  int IP;     /* I rounded up to 32                                            */
+  int HP;     /* H rounded up to 64                                            */
+  int ZP;     /* Z rounded up to 64                                            */
+} dvae_svae_dims;
+int dvae_svae_dims_init(dvae_svae_dims* d);
+
+/* packing: as dvae_enc_pack_table / dvae_dec_pack_table above (canonical tensor order in
+ * INTEGRATION.md); the packed gradient buffer has the size and layout of the packed
+ * parameters.  Pack / unpack with dvae_pack_params / dvae_unpack_grads. */
+size_t dvae_svae_enc_param_floats(const dvae_svae_dims* d);
+size_t dvae_svae_dec_param_floats(const dvae_svae_dims* d);
+int dvae_svae_enc_param_count(const dvae_svae_dims* d);
+int dvae_svae_dec_param_count(const dvae_svae_dims* d);
+int dvae_svae_enc_pack_table(const dvae_svae_dims* d, const uint64_t* raw_host, const int64_t* grad_off_host,
+                             dvae_pack_entry* table_host, int max_entries);
+int dvae_svae_dec_pack_table(const dvae_svae_dims* d, const uint64_t* raw_host, const int64_t* grad_off_host,
+                             dvae_pack_entry* table_host, int max_entries);
+
+/* Encoder.forward (svae_model.py:35-44): x [B][T][I] -> mu, logvar [B][Z].
+ * ws: dvae_svae_enc_ws_bytes(d) bytes, kept by the caller until the backward call. */
+size_t dvae_svae_enc_ws_bytes(const dvae_svae_dims* d);
+int dvae_svae_enc_fwd(const dvae_svae_dims* d, const float* x, const float* P, void* ws, float* mu,
+                      float* logvar, void* stream);
+/* d_mu / d_logvar [B][Z] (either may be NULL); G: packed gradients out (every entry written) */
+int dvae_svae_enc_bwd(const dvae_svae_dims* d, const float* P, void* ws, const float* d_mu,
+                      const float* d_logvar, float* G, void* stream);
+
+/* Decoder.forward (svae_model.py:73-79): z [B][Z] -> type_scores [B][T][C], edge_scores [B][T][N] */
+size_t dvae_svae_dec_ws_bytes(const dvae_svae_dims* d);
+int dvae_svae_dec_fwd(const dvae_svae_dims* d, const float* z, const float* P, void* ws,
+                      float* type_scores, float* edge_scores, void* stream);
+int dvae_svae_dec_bwd(const dvae_svae_dims* d, const float* P, void* ws, const float* d_type_scores,
+                      const float* d_edge_scores, float* G, float* d_z, void* stream);
+
+/* Losses of Svae.training_step / validation_step (svae_model.py:171-182, 210-221): BCE-with-logits
+ * (sum) of edge_scores against the parent flags x[..., C:], cross entropy (sum) of type_scores
+ * against argmax x[..., :C], KL.  out4 = {edge_loss, vertex_loss, kl_loss, loss}; gradients of
+ * `loss` are written when the d_* pointers are non-NULL.  partial: dvae_elbo_ws_bytes(B) bytes. */
+int dvae_svae_elbo(const dvae_svae_dims* d, const float* type_scores, const float* edge_scores,
+                   const float* x, const float* mu, const float* logvar, float beta, float* out4,
+                   void* partial, float* d_type, float* d_edge, float* d_mu, float* d_logvar,
+                   void* stream);
+
+/* Svae._predict_from_logits (svae_model.py:112-131) over rows = B*T score rows: greedy (argmax,
+ * sigmoid > 0.5) when u_type / u_edge are NULL, otherwise inverse-CDF draws from the injected
+ * uniforms u_type [rows], u_edge [rows][N] (the reference draws with torch.multinomial /
+ * torch.bernoulli).  onehot [rows][C], flags [rows][N], both exact 0/1. */
+int dvae_svae_predict(const dvae_svae_dims* d, long long rows, const float* type_scores,
+                      const float* edge_scores, const float* u_type, const float* u_edge,
+                      float* onehot, float* flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,174 @@
+"""GPU: the S-VAE baseline on the HIP path (csrc/svae.hip through the C ABI) against the golden
+vectors of the real reference and against oracle/svae_ref.py.  rtol 1e-4 (north_star) on scores,
+losses and gradients; decisions bit-exact where their margin is above fp32 noise."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import close_scaled, fill_weights, oracle_sd
+from test_svae_oracle import SVAE_CASES, build_svae, check_grads_against_golden, load_svae_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", SVAE_CASES)
+def test_hip_matches_reference(cuda, name):
+    d, bidir, C, N = load_svae_case(name)
+    model = build_svae(d, bidir, C, N, cuda)
+    x, eps = torch.from_numpy(d['x']).to(cuda), torch.from_numpy(d['eps']).to(cuda)
+    with torch.no_grad():
+        mu, lv = model.encoder(x)
+        close_scaled(mu, torch.from_numpy(d['mu']), what="mu")
+        close_scaled(lv, torch.from_numpy(d['logvar']), what="logvar")
+        ts, es = model.decoder(torch.from_numpy(d['z']).to(cuda))
+        close_scaled(ts, torch.from_numpy(d['type_scores']), what="type scores")
+        close_scaled(es, torch.from_numpy(d['edge_scores']), what="edge scores")
+        # decisions on the reference's own scores: bit-exact away from ties
+        gts, ges = torch.from_numpy(d['type_scores']), torch.from_numpy(d['edge_scores'])
+        onehot, flags = model._predict_from_logits(gts.to(cuda), ges.to(cuda))
+        top = torch.topk(gts, 2, dim=-1).values
+        sure_t = (top[..., 0] - top[..., 1]) > 1e-4
+        sure_e = ges.abs() > 1e-4
+        assert sure_t.sum() > 0.8 * sure_t.numel() and sure_e.sum() > 0.8 * sure_e.numel()
+        assert np.array_equal(onehot.cpu().numpy()[sure_t.numpy()], d['onehot'][sure_t.numpy()])
+        assert np.array_equal(flags.cpu().numpy()[sure_e.numpy()], d['flags'][sure_e.numpy()])
+    out = model.training_step({'graph': x}, 0, eps=eps)
+    got = [float(out['log'][k]) for k in ('train/edge_loss', 'train/vertex_loss', 'train/kl_loss', 'train/loss')]
+    np.testing.assert_allclose(got, d['losses'], rtol=1e-4)
+    assert abs(float(out['log']['train/acc']) - float(d['acc'])) < 1e-6
+    out['loss'].backward()
+    check_grads_against_golden([(k, p.grad) for k, p in model.named_parameters()], d)
+
+
+@pytest.mark.parametrize("B,C,N,H,bidir", [(64, 8, 8, 501, True), (33, 6, 12, 200, False), (5, 10, 10, 64, True),
+                                           (1, 8, 2, 501, True), (300, 8, 8, 128, False)])
+def test_hip_matches_oracle(cuda, B, C, N, H, bidir):
+    """Every output and every gradient against the oracle, including odd sizes (one string, one step,
+    hidden widths that are / are not multiples of 64)."""
+    import dvae_amd
+    from dvae_amd import svae as S
+    from oracle import svae_ref as O
+    torch.manual_seed(3)
+    model = dvae_amd.Svae(Namespace(dataset_file=None, bidirectional=bidir, num_classes=C, max_seq=N))
+    model.encoder = S.Encoder(C, N, hidden_size=H, bidir=bidir)
+    model.decoder = S.Decoder(C, N, hidden_size=H)
+    fill_weights(model, 17)
+    model.to(cuda)
+    T = N - 1
+    sd0 = oracle_sd(model)
+    for seed in range(200):     # inputs on which no ReLU sits within fp32 noise of its kink (oracle relu_margin)
+        gen = torch.Generator().manual_seed(1000 * B + seed)
+        x = torch.cat((torch.nn.functional.one_hot(torch.randint(0, C, (B, T), generator=gen), C).float(),
+                       (torch.rand(B, T, N, generator=gen) < 0.4).float()), dim=-1)
+        eps = torch.randn(B, 56, generator=gen)
+        with torch.no_grad():
+            mu0, lv0 = O.encoder(sd0, x, bidir)
+            if O.relu_margin(sd0, eps * torch.exp(0.5 * lv0) + mu0, T) > 1e-6:
+                break
+    else:
+        pytest.fail("no input with a safe ReLU margin")
+    sd = oracle_sd(model, requires_grad=True)
+    ref = O.train_loss(sd, x, eps, bidir, C)
+    ref[0].backward()
+    out = model.training_step({'graph': x.to(cuda)}, 0, eps=eps.to(cuda))
+    got = [float(out['log'][k]) for k in ('train/edge_loss', 'train/vertex_loss', 'train/kl_loss', 'train/loss')]
+    np.testing.assert_allclose(got, [float(ref[1]), float(ref[2]), float(ref[3]), float(ref[0])], rtol=1e-4)
+    out['loss'].backward()
+    for k, p in model.named_parameters():
+        close_scaled(p.grad, sd[k].grad, tol=3e-4, what=k)
+    with torch.no_grad():
+        ts, es, mu, lv = model(x.to(cuda), eps=eps.to(cuda))
+    for a, b, what in ((ts, ref[6], "type scores"), (es, ref[7], "edge scores"), (mu, ref[4], "mu"), (lv, ref[5], "logvar")):
+        close_scaled(a, b, what=what)
+
+
+def test_gradients_through_the_pieces(cuda):
+    """encoder / decoder Functions with arbitrary upstream gradients (not only the ELBO's), d_z included."""
+    from oracle import svae_ref as O
+    d, bidir, C, N = load_svae_case("svae_rand10_bidir")
+    model = build_svae(d, bidir, C, N, cuda)
+    sd = oracle_sd(model, requires_grad=True)
+    x = torch.from_numpy(d['x'])
+    gen = torch.Generator().manual_seed(9)
+    z = torch.randn(x.shape[0], 56, generator=gen).requires_grad_(True)
+    wt, we = torch.randn(x.shape[0], N - 1, C, generator=gen), torch.randn(x.shape[0], N - 1, N, generator=gen)
+    wm, wl = torch.randn(x.shape[0], 56, generator=gen), torch.randn(x.shape[0], 56, generator=gen)
+    ts, es = O.decoder(sd, z, N - 1)
+    mu, lv = O.encoder(sd, x, bidir)
+    ((ts * wt).sum() + (es * we).sum() + (mu * wm).sum() + (lv * wl).sum()).backward()
+    zc = z.detach().to(cuda).requires_grad_(True)
+    hts, hes = model.decoder(zc)
+    hmu, hlv = model.encoder(x.to(cuda))
+    ((hts * wt.to(cuda)).sum() + (hes * we.to(cuda)).sum() + (hmu * wm.to(cuda)).sum() + (hlv * wl.to(cuda)).sum()).backward()
+    close_scaled(zc.grad, z.grad, tol=3e-4, what="d_z")
+    for k, p in model.named_parameters():
+        close_scaled(p.grad, sd[k].grad, tol=3e-4, what=k)
+    # only one of the two heads / outputs used
+    model.zero_grad()
+    for k in sd:
+        sd[k].grad = None
+    (O.decoder(sd, z, N - 1)[1] * we).sum().backward()
+    (O.encoder(sd, x, bidir)[0] * wm).sum().backward()
+    (model.decoder(zc)[1] * we.to(cuda)).sum().backward()
+    (model.encoder(x.to(cuda))[0] * wm.to(cuda)).sum().backward()
+    for k, p in model.named_parameters():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        close_scaled(p.grad, ref, tol=3e-4, what=k)
+
+
+def test_stochastic_decisions_with_injected_uniforms(cuda):
+    from oracle import svae_ref as O
+    d, bidir, C, N = load_svae_case("svae_enas_val8_uni")
+    model = build_svae(d, bidir, C, N, cuda)
+    gen = torch.Generator().manual_seed(4)
+    ts, es = 2 * torch.randn(500, 7, C, generator=gen), 2 * torch.randn(500, 7, N, generator=gen)
+    ut, ue = torch.rand(500, 7, generator=gen), torch.rand(500, 7, N, generator=gen)
+    onehot, flags = model._predict_from_logits(ts.to(cuda), es.to(cuda), is_stochastic=True,
+                                               uniforms=(ut.to(cuda), ue.to(cuda)))
+    ro, rf = O.predict_from_logits(ts, es, ut, ue)
+    # a draw within fp32 noise of a CDF step may land on either side
+    e = torch.exp(ts - ts.max(-1, keepdim=True).values)
+    cdf = torch.cumsum(e, -1)
+    sure_t = ((cdf - (ut * e.sum(-1)).unsqueeze(-1)).abs() > 1e-4).all(-1)
+    sure_e = (ue - torch.sigmoid(es)).abs() > 1e-5
+    assert sure_t.float().mean() > 0.99 and sure_e.float().mean() > 0.99
+    assert torch.equal(onehot.cpu()[sure_t], ro[sure_t]) and torch.equal(flags.cpu()[sure_e], rf[sure_e])
+    assert set(onehot.unique().tolist()) <= {0.0, 1.0} and bool((onehot.sum(-1) == 1).all())
+    # frequencies follow the probabilities
+    big = torch.zeros(20000, 1, C)
+    big[..., 1] = 1.0
+    oh, _ = model._predict_from_logits(big.to(cuda), torch.zeros(20000, 1, N, device=cuda), is_stochastic=True)
+    p1 = float(torch.softmax(big[0, 0], -1)[1])
+    assert abs(float(oh[..., 1].mean()) - p1) < 0.02
+
+
+def test_eval_predict_and_training_loop(cuda):
+    """predict / model_eval / validation hooks run on real ENAS strings and a short Adam run lowers the loss."""
+    d, bidir, C, N = load_svae_case("svae_enas_val8_bidir")
+    model = build_svae(d, bidir, C, N, cuda)
+    x = torch.from_numpy(d['x']).to(cuda)
+    flags, onehot = model.predict(x)                      # the reference returns (parent flags, one-hot types)
+    assert flags.shape == (8, 7, 8) and onehot.shape == (8, 7, 8) and bool((onehot.sum(-1) == 1).all())
+    r = model.model_eval({'graph': x}, 3, 2)
+    assert 0.0 <= r['recon_acc'] <= 1.0
+    v = model.validation_end([model.validation_step({'graph': x}, 0), model.validation_step({'graph': x}, 1)])
+    assert set(v['log']) == {"val_loss", "val/edge_loss", "val/vertex_loss", "val/kl_loss", "val/acc"}
+    (opt,), _ = model.configure_optimizers()
+    first = last = None
+    for step in range(30):
+        opt.zero_grad()
+        out = model.training_step({'graph': x}, step)
+        out['loss'].backward()
+        opt.step()
+        last = float(out['loss'])
+        first = last if first is None else first
+    assert last < 0.7 * first, (first, last)
+    # an over-fitted model reconstructs its training strings greedily
+    for step in range(400):
+        opt.zero_grad()
+        out = model.training_step({'graph': x}, step)
+        out['loss'].backward()
+        opt.step()
+    assert float(out['log']['train/acc']) >= 0.5

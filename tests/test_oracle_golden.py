@@ -31,7 +31,8 @@ def build_model(d, mod, bidir, shared, device=None):
 
 def test_fixture_inventory():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
-    assert names == sorted(TRAIN_CASES + ["predict_none", "predict_bn", "enas_rows"])
+    svae = ["svae_enas_val8_uni", "svae_enas_val8_bidir", "svae_rand10_bidir"]      # test_svae_oracle.py
+    assert names == sorted(TRAIN_CASES + ["predict_none", "predict_bn", "enas_rows"] + svae)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
