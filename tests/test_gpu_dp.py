@@ -61,3 +61,51 @@ def test_two_ranks_equal_the_big_batch():
         assert ret['rows'] == 6
         assert ret['loss_err'] < 1e-5, ret['loss_err']
         assert ret['grad_rel'] < 1e-5 and ret['grad_max'] < 1e-4, dict(ret)
+
+
+def _svae_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dvae_amd
+    from dvae_amd import dp
+    from helpers import fill_weights
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    model = fill_weights(dvae_amd.Svae(Namespace(dataset_file=None, bidirectional=True, num_classes=6, max_seq=8)), 9).to(dev)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.cat((torch.nn.functional.one_hot(torch.randint(0, 6, (11, 7), generator=gen), 6).float(),
+                   (torch.rand(11, 7, 8, generator=gen) < 0.4).float()), dim=-1)
+    eps = torch.randn(11, 56, generator=gen)                                   # drawn per GLOBAL string index
+    full = {'graph': x.to(dev), 'eps': eps.to(dev)}
+    mine = dp.shard_batch(full, rank, world)
+    out = model.training_step(mine, 0, eps=mine['eps'])
+    out['loss'].backward()
+    sync = dp.make_grad_sync(dist)
+    for p in model.parameters():                                               # the Trainer's rule: SUM all-reduce
+        sync(p.grad).wait()
+    loss = dp.allreduce_losses(dist, out['loss'].detach().reshape(1).clone())
+    torch.cuda.synchronize()
+    grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    if rank == 0:
+        model.zero_grad()
+        ref_out = model.training_step(full, 0, eps=full['eps'])
+        ref_out['loss'].backward()
+        ref = torch.cat([p.grad.flatten() for p in model.parameters()])
+        ret['grad_rel'] = float((grads - ref).norm() / ref.norm())
+        ret['loss_err'] = float((loss[0] - ref_out['loss']).abs() / ref_out['loss'].abs())
+        ret['rows'] = int(mine['graph'].shape[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_svae_two_ranks_equal_the_big_batch():
+    world = 2
+    port = 33500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_svae_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert ret['rows'] == 6
+        assert ret['loss_err'] < 1e-5 and ret['grad_rel'] < 1e-5, dict(ret)
