@@ -198,3 +198,32 @@ def test_trainer_fits_real_enas_strings(cuda, tmp_path):
     torch.manual_seed(5); v1 = float(t.validate(model)['avg_val_loss'])
     torch.manual_seed(5); v2 = float(t.validate(again)['avg_val_loss'])
     assert abs(v1 - v2) <= 1e-6 * abs(v1)
+
+
+def test_full_size_batch_is_the_sum_of_its_shards(cuda):
+    """B = 4096 ENAS-8 strings (the bench shape), too large for the oracle in seconds: the losses are sums over
+    strings, so loss and every gradient of the whole batch equal the sums over four shards of 1024, and the
+    scores of a string do not depend on what else is in the batch."""
+    import dvae_amd
+    torch.manual_seed(0)
+    model = dvae_amd.Svae(Namespace(dataset_file=None, bidirectional=True)).to(cuda)
+    gen = torch.Generator().manual_seed(11)
+    B, C, N, T = 4096, 8, 8, 7
+    x = torch.cat((torch.nn.functional.one_hot(torch.randint(0, C, (B, T), generator=gen), C).float(),
+                   (torch.rand(B, T, N, generator=gen) < 0.5).float()), dim=-1).to(cuda)
+    eps = torch.randn(B, 56, generator=gen).to(cuda)
+    out = model.training_step({'graph': x}, 0, eps=eps)
+    out['loss'].backward()
+    whole = {k: p.grad.clone() for k, p in model.named_parameters()}
+    ts_whole = model(x, eps=eps)[0].detach()
+    model.zero_grad()
+    total = 0.0
+    for s in range(4):
+        sl = slice(1024 * s, 1024 * (s + 1))
+        o = model.training_step({'graph': x[sl]}, 0, eps=eps[sl])
+        o['loss'].backward()                      # gradients accumulate over the shards
+        total += float(o['loss'])
+        close_scaled(model(x[sl], eps=eps[sl])[0], ts_whole[sl], tol=1e-5, what="scores of shard %d" % s)
+    assert abs(total - float(out['loss'])) <= 1e-5 * abs(total)
+    for k, p in model.named_parameters():
+        close_scaled(p.grad, whole[k], tol=3e-4, what=k)      # the gradient tolerance of every test here
