@@ -104,9 +104,9 @@ SIGNATURES = {
     "dvae_svae_enc_ws_bytes": (c_size_t, [_P(SvaeDims)]),
     "dvae_svae_dec_ws_bytes": (c_size_t, [_P(SvaeDims)]),
     "dvae_svae_enc_fwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 6),
-    "dvae_svae_enc_bwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 6),
+    "dvae_svae_enc_bwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 7),
     "dvae_svae_dec_fwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 6),
-    "dvae_svae_dec_bwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 7),
+    "dvae_svae_dec_bwd": (c_int, [_P(SvaeDims)] + [c_void_p] * 8),
     "dvae_svae_elbo": (c_int, [_P(SvaeDims)] + [c_void_p] * 5 + [c_float] + [c_void_p] * 7),
     "dvae_svae_predict": (c_int, [_P(SvaeDims), c_ll] + [c_void_p] * 7),
     "dvae_side_stream_create": (c_int, [_P(c_void_p), _P(c_int)]),

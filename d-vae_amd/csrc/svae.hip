@@ -5,6 +5,7 @@
 // step's hidden product is one GEMM over B rows; whole-sequence products (input projection, heads,
 // every weight gradient) are single GEMMs over T*B rows.
 #include <algorithm>
+#include <vector>
 
 #include "kernels.h"
 #include "svae_layout.h"
@@ -40,6 +41,7 @@ struct EncWs {
   float* DCAT;   // [B][2HP]
   float* CARRY;  // [B][HP]
   float* gemm_ws; float* part;
+  float* gemm_ws2; float* part2;   // the side stream's scratch
   size_t bytes;
 };
 
@@ -66,6 +68,8 @@ EncWs enc_ws(const dvae_svae_dims& d, void* base) {
   w.CARRY = c.take((size_t)d.B * d.HP);
   w.gemm_ws = c.take(SVAE_GEMM_WS / 4);
   w.part = c.take(SVAE_PART_FLOATS);
+  w.gemm_ws2 = c.take(SVAE_GEMM_WS / 4);
+  w.part2 = c.take(SVAE_PART_FLOATS);
   w.bytes = c.off;
   return w;
 }
@@ -84,6 +88,7 @@ struct DecWs {
   float* DH0;    // [B][HP]
   float* DZT;    // [B][ZP]
   float* gemm_ws; float* part;
+  float* gemm_ws2; float* part2;   // the side stream's scratch
   size_t bytes;
 };
 
@@ -105,9 +110,32 @@ DecWs dec_ws(const dvae_svae_dims& d, void* base) {
   w.DZT = c.take((size_t)d.B * d.ZP);
   w.gemm_ws = c.take(SVAE_GEMM_WS / 4);
   w.part = c.take(SVAE_PART_FLOATS);
+  w.gemm_ws2 = c.take(SVAE_GEMM_WS / 4);
+  w.part2 = c.take(SVAE_PART_FLOATS);
   w.bytes = c.off;
   return w;
 }
+
+// `to` continues after what `from` has queued so far (events from a small per-thread ring)
+struct EventRing {
+  std::vector<hipEvent_t> ev;
+  size_t next = 0;
+  int edge(hipStream_t from, hipStream_t to) {
+    if (from == to) return DVAE_OK;
+    if (ev.size() < 64) {
+      hipEvent_t e;
+      DVAE_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev.push_back(e);
+      next = ev.size() - 1;
+    } else {
+      next = (next + 1) % ev.size();
+    }
+    DVAE_CHECK_HIP(hipEventRecord(ev[next], from));
+    DVAE_CHECK_HIP(hipStreamWaitEvent(to, ev[next], 0));
+    return DVAE_OK;
+  }
+};
+thread_local EventRing g_ring;
 
 struct G {
   float* ws; hipStream_t st;
@@ -283,12 +311,17 @@ int gru_seq_bwd(const dvae_svae_dims& d, const G& g, const float* P, const SvaeG
   return DVAE_OK;
 }
 
-// weight gradients of one GRU whose input rows are X [rows_x][KP] paired with DGI
-int gru_wgrad(const dvae_svae_dims& d, const G& g, const SvaeGru& w, const GruTables& t, const float* DGI,
-              const float* X, int KP, int rows_x, float* Gp, float* part) {
+// weight gradients of one GRU: the hidden half (states x d(hidden product), both step-major) ...
+int gru_wgrad_hh(const dvae_svae_dims& d, const G& g, const SvaeGru& w, const GruTables& t, float* Gp, float* part) {
   const int HP = d.HP, TB = d.T * d.B;
   DVAE_TRY(g.tn(t.GATES, 3 * HP, t.HALL, HP, Gp + w.Whh, HP, 3 * HP, HP, TB));
   DVAE_TRY(k_colsum(t.GATES, 3 * HP, TB, 3 * HP, Gp + w.bhh, part, SVAE_PART_FLOATS, g.st));
+  return DVAE_OK;
+}
+// ... and the input half: input rows X [rows_x][KP] paired with DGI
+int gru_wgrad_ih(const dvae_svae_dims& d, const G& g, const SvaeGru& w, const float* DGI, const float* X, int KP,
+                 int rows_x, float* Gp, float* part) {
+  const int HP = d.HP;
   DVAE_TRY(g.tn(DGI, 3 * HP, X, KP, Gp + w.Wih, KP, 3 * HP, KP, rows_x));
   DVAE_TRY(k_colsum(DGI, 3 * HP, rows_x, 3 * HP, Gp + w.bih, part, SVAE_PART_FLOATS, g.st));
   return DVAE_OK;
@@ -341,24 +374,29 @@ extern "C" int dvae_svae_enc_fwd(const dvae_svae_dims* dp, const float* x, const
 }
 
 extern "C" int dvae_svae_enc_bwd(const dvae_svae_dims* dp, const float* P, void* ws, const float* d_mu,
-                                 const float* d_logvar, float* Gp, void* stream) {
+                                 const float* d_logvar, float* Gp, void* stream, void* side_stream) {
   DVAE_TRY(check_dims(dp));
   DVAE_REQUIRE(P && ws && Gp, "svae_enc_bwd: null pointer");
   const dvae_svae_dims& d = *dp;
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;   // weight gradients run beside the chain
   const EncWs w = enc_ws(d, ws);
   const SvaeEncLayout L = svae_enc_layout(d);
   const G g{w.gemm_ws, st};
+  const G gs{sd == st ? w.gemm_ws : w.gemm_ws2, sd};
+  float* spart = sd == st ? w.part : w.part2;
   const int B = d.B, HP = d.HP, ZP = d.ZP, TB = d.T * d.B;
   const float* hn = d.bidir ? w.HN : w.g[0].HALL + (size_t)TB * HP;
   hipLaunchKernelGGL(ml_pack_kernel, grid_of((long long)B * 2 * ZP), dim3(256), 0, st, d_mu, d_logvar, B, d.Z, ZP, w.ML);
   DVAE_LAUNCH_CHECK();
-  DVAE_TRY(g.tn(w.ML, 2 * ZP, hn, HP, Gp + L.Wml, HP, 2 * ZP, HP, B));
-  DVAE_TRY(k_colsum(w.ML, 2 * ZP, B, 2 * ZP, Gp + L.bml, w.part, SVAE_PART_FLOATS, st));
+  DVAE_TRY(g_ring.edge(st, sd));
+  DVAE_TRY(gs.tn(w.ML, 2 * ZP, hn, HP, Gp + L.Wml, HP, 2 * ZP, HP, B));
+  DVAE_TRY(k_colsum(w.ML, 2 * ZP, B, 2 * ZP, Gp + L.bml, spart, SVAE_PART_FLOATS, sd));
   DVAE_TRY(g.nn(w.ML, 2 * ZP, P + L.Wml, HP, w.DHN, HP, B, HP, 2 * ZP));
   if (d.bidir) {
-    DVAE_TRY(g.tn(w.DHN, HP, w.CAT, 2 * HP, Gp + L.Wun, 2 * HP, HP, 2 * HP, B));
-    DVAE_TRY(k_colsum(w.DHN, HP, B, HP, Gp + L.bun, w.part, SVAE_PART_FLOATS, st));
+    DVAE_TRY(g_ring.edge(st, sd));
+    DVAE_TRY(gs.tn(w.DHN, HP, w.CAT, 2 * HP, Gp + L.Wun, 2 * HP, HP, 2 * HP, B));
+    DVAE_TRY(k_colsum(w.DHN, HP, B, HP, Gp + L.bun, spart, SVAE_PART_FLOATS, sd));
     DVAE_TRY(g.nn(w.DHN, HP, P + L.Wun, 2 * HP, w.DCAT, 2 * HP, B, 2 * HP, HP));
   }
   for (int dir = 0; dir < (d.bidir ? 2 : 1); ++dir) {
@@ -366,7 +404,9 @@ extern "C" int dvae_svae_enc_bwd(const dvae_svae_dims* dp, const float* P, void*
     DVAE_CHECK_HIP(hipMemcpy2DAsync(w.CARRY, (size_t)HP * 4, src, (size_t)(d.bidir ? 2 : 1) * HP * 4, (size_t)HP * 4,
                                     B, hipMemcpyDeviceToDevice, st));
     DVAE_TRY(gru_seq_bwd(d, g, P, L.gru[dir], w.g[dir], nullptr, w.CARRY, dir == 1));
-    DVAE_TRY(gru_wgrad(d, g, L.gru[dir], w.g[dir], w.g[dir].GI, w.XT, d.IP, TB, Gp, w.part));
+    DVAE_TRY(g_ring.edge(st, sd));
+    DVAE_TRY(gru_wgrad_hh(d, gs, L.gru[dir], w.g[dir], Gp, spart));
+    DVAE_TRY(gru_wgrad_ih(d, gs, L.gru[dir], w.g[dir].GI, w.XT, d.IP, TB, Gp, spart));
   }
   return DVAE_OK;
 }
@@ -397,41 +437,50 @@ extern "C" int dvae_svae_dec_fwd(const dvae_svae_dims* dp, const float* z, const
 }
 
 extern "C" int dvae_svae_dec_bwd(const dvae_svae_dims* dp, const float* P, void* ws, const float* d_type,
-                                 const float* d_edge, float* Gp, float* d_z, void* stream) {
+                                 const float* d_edge, float* Gp, float* d_z, void* stream, void* side_stream) {
   DVAE_TRY(check_dims(dp));
   DVAE_REQUIRE(P && ws && Gp, "svae_dec_bwd: null pointer");
   const dvae_svae_dims& d = *dp;
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;   // weight gradients run beside the chain
   const DecWs w = dec_ws(d, ws);
   const SvaeDecLayout L = svae_dec_layout(d);
   const G g{w.gemm_ws, st};
+  const G gs{sd == st ? w.gemm_ws : w.gemm_ws2, sd};
+  float* spart = sd == st ? w.part : w.part2;
   const int B = d.B, HP = d.HP, TB = d.T * d.B;
   const float* hout = w.g.HALL + (size_t)B * HP;
   hipLaunchKernelGGL(bt_to_tm_kernel, grid_of((long long)TB * 32), dim3(256), 0, st, d_type, B, d.T, d.C, 0, d.C, w.TS, 32, 32);
   DVAE_LAUNCH_CHECK();
   hipLaunchKernelGGL(bt_to_tm_kernel, grid_of((long long)TB * 32), dim3(256), 0, st, d_edge, B, d.T, d.N, 0, d.N, w.ES, 32, 32);
   DVAE_LAUNCH_CHECK();
-  // heads
-  DVAE_TRY(g.tn(w.TS, 32, w.HID, 2 * HP, Gp + L.Wv2, HP, 32, HP, TB));
-  DVAE_TRY(g.tn(w.ES, 32, w.HID + HP, 2 * HP, Gp + L.We2, HP, 32, HP, TB));
-  DVAE_TRY(k_colsum(w.TS, 32, TB, 32, Gp + L.bv2, w.part, SVAE_PART_FLOATS, st));
-  DVAE_TRY(k_colsum(w.ES, 32, TB, 32, Gp + L.be2, w.part, SVAE_PART_FLOATS, st));
+  // heads (weight gradients on the side stream, the input-gradient chain on the caller's)
+  DVAE_TRY(g_ring.edge(st, sd));
+  DVAE_TRY(gs.tn(w.TS, 32, w.HID, 2 * HP, Gp + L.Wv2, HP, 32, HP, TB));
+  DVAE_TRY(gs.tn(w.ES, 32, w.HID + HP, 2 * HP, Gp + L.We2, HP, 32, HP, TB));
+  DVAE_TRY(k_colsum(w.TS, 32, TB, 32, Gp + L.bv2, spart, SVAE_PART_FLOATS, sd));
+  DVAE_TRY(k_colsum(w.ES, 32, TB, 32, Gp + L.be2, spart, SVAE_PART_FLOATS, sd));
   DVAE_TRY(g.nn(w.TS, 32, P + L.Wv2, HP, w.DHID, 2 * HP, TB, HP, 32));
   DVAE_TRY(g.nn(w.ES, 32, P + L.We2, HP, w.DHID + HP, 2 * HP, TB, HP, 32));
   DVAE_TRY(k_relu_bwd_colsum(w.DHID, w.HID, 2 * HP, TB, 2 * HP, Gp + L.b1, w.part, SVAE_PART_FLOATS, st));
-  DVAE_TRY(g.tn(w.DHID, 2 * HP, hout, HP, Gp + L.W1, HP, 2 * HP, HP, TB));
+  DVAE_TRY(g_ring.edge(st, sd));
+  DVAE_TRY(gs.tn(w.DHID, 2 * HP, hout, HP, Gp + L.W1, HP, 2 * HP, HP, TB));
   DVAE_TRY(g.nn(w.DHID, 2 * HP, P + L.W1, HP, w.DHOUT, HP, TB, HP, 2 * HP));
   // GRU through time
   DVAE_TRY(k_zero(w.CARRY, (size_t)B * HP * 4, st));
   DVAE_TRY(gru_seq_bwd(d, g, P, L.gru, w.g, w.DHOUT, w.CARRY, false));
+  DVAE_TRY(g_ring.edge(st, sd));
+  DVAE_TRY(gru_wgrad_hh(d, gs, L.gru, w.g, Gp, spart));
   hipLaunchKernelGGL(sum_slabs_kernel, grid_of((long long)B * 3 * HP), dim3(256), 0, st, w.g.GI, (size_t)B * 3 * HP,
                      d.T, w.GI0);
   DVAE_LAUNCH_CHECK();
-  DVAE_TRY(gru_wgrad(d, g, L.gru, w.g, w.GI0, w.H0, HP, B, Gp, w.part));
+  DVAE_TRY(g_ring.edge(st, sd));
+  DVAE_TRY(gru_wgrad_ih(d, gs, L.gru, w.GI0, w.H0, HP, B, Gp, spart));
   // fc_h0
   DVAE_TRY(g.nn(w.GI0, 3 * HP, P + L.gru.Wih, HP, w.DH0, HP, B, HP, 3 * HP));
   DVAE_TRY(k_relu_bwd_colsum(w.DH0, w.H0, HP, B, HP, Gp + L.bh0, w.part, SVAE_PART_FLOATS, st));
-  DVAE_TRY(g.tn(w.DH0, HP, w.ZT, d.ZP, Gp + L.Wh0, d.ZP, HP, d.ZP, B));
+  DVAE_TRY(g_ring.edge(st, sd));
+  DVAE_TRY(gs.tn(w.DH0, HP, w.ZT, d.ZP, Gp + L.Wh0, d.ZP, HP, d.ZP, B));
   if (d_z) {
     DVAE_TRY(g.nn(w.DH0, HP, P + L.Wh0, d.ZP, w.DZT, d.ZP, B, d.ZP, HP));
     DVAE_TRY(k_unpad_rows(w.DZT, d.ZP, B, d.Z, d_z, st));

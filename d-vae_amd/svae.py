@@ -43,6 +43,16 @@ class GruWeights(nn.Module):
         return [getattr(self, n + s) for n in ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0')]
 
 
+TWO_STREAMS = True      # weight-gradient products on the library's side stream (False: one stream; tests)
+
+
+def _two_streams(pack, G, run):
+    if TWO_STREAMS:
+        return E._bwd_on_two_streams(pack, G, run)
+    res = run(None)
+    return pack.unpack(G), res
+
+
 def _dims(d0, B, T):
     return _lib.make_svae_dims(B, T, d0.C, d0.N, d0.H, d0.Z, d0.bidir)
 
@@ -67,9 +77,11 @@ class _EncFn(torch.autograd.Function):
         G = torch.empty(pack.gfloats, dtype=torch.float32, device=ctx.P.device)
         cont = lambda t: None if t is None else t.contiguous()
         d_mu, d_logvar = cont(d_mu), cont(d_logvar)
-        check(load().dvae_svae_enc_bwd(ctypes.byref(ctx.d), _ptr(ctx.P), _ptr(ctx.ws), _ptr(d_mu), _ptr(d_logvar),
-                                       _ptr(G), _stream()))
-        grads = pack.views(pack.unpack(G), ctx.params)
+        run = lambda side: check(load().dvae_svae_enc_bwd(
+            ctypes.byref(ctx.d), _ptr(ctx.P), _ptr(ctx.ws), _ptr(d_mu), _ptr(d_logvar), _ptr(G), _stream(),
+            E._side(side)))
+        flat = _two_streams(pack, G, run)[0]
+        grads = pack.views(flat, ctx.params)
         ctx.ws = None
         return (None, None) + tuple(grads)
 
@@ -97,9 +109,11 @@ class _DecFn(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         d_ts, d_es = cont(d_ts), cont(d_es)
         d_z = torch.empty(d.B, d.Z, device=ctx.P.device)
-        check(load().dvae_svae_dec_bwd(ctypes.byref(d), _ptr(ctx.P), _ptr(ctx.ws), _ptr(d_ts), _ptr(d_es), _ptr(G),
-                                       _ptr(d_z), _stream()))
-        grads = pack.views(pack.unpack(G), ctx.params)
+        run = lambda side: check(load().dvae_svae_dec_bwd(
+            ctypes.byref(d), _ptr(ctx.P), _ptr(ctx.ws), _ptr(d_ts), _ptr(d_es), _ptr(G), _ptr(d_z), _stream(),
+            E._side(side)))
+        flat = _two_streams(pack, G, run)[0]
+        grads = pack.views(flat, ctx.params)
         ctx.ws = None
         return (None, d_z) + tuple(grads)
 

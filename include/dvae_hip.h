@@ -313,16 +313,19 @@ int dvae_svae_dec_pack_table(const dvae_svae_dims* d, const uint64_t* raw_host, 
 size_t dvae_svae_enc_ws_bytes(const dvae_svae_dims* d);
 int dvae_svae_enc_fwd(const dvae_svae_dims* d, const float* x, const float* P, void* ws, float* mu,
                       float* logvar, void* stream);
-/* d_mu / d_logvar [B][Z] (either may be NULL); G: packed gradients out (every entry written) */
+/* d_mu / d_logvar [B][Z] (either may be NULL); G: packed gradients out (every entry written).
+ * side_stream (hipStream_t or NULL), here and in dvae_svae_dec_bwd: when given, the weight-gradient products
+ * are issued there beside the through-time chain, ordered with events; on return it may still hold work
+ * that writes G, so the caller orders its next use of G after it (as for dvae_encoder_bwd). */
 int dvae_svae_enc_bwd(const dvae_svae_dims* d, const float* P, void* ws, const float* d_mu,
-                      const float* d_logvar, float* G, void* stream);
+                      const float* d_logvar, float* G, void* stream, void* side_stream);
 
 /* Decoder.forward (svae_model.py:73-79): z [B][Z] -> type_scores [B][T][C], edge_scores [B][T][N] */
 size_t dvae_svae_dec_ws_bytes(const dvae_svae_dims* d);
 int dvae_svae_dec_fwd(const dvae_svae_dims* d, const float* z, const float* P, void* ws,
                       float* type_scores, float* edge_scores, void* stream);
 int dvae_svae_dec_bwd(const dvae_svae_dims* d, const float* P, void* ws, const float* d_type_scores,
-                      const float* d_edge_scores, float* G, float* d_z, void* stream);
+                      const float* d_edge_scores, float* G, float* d_z, void* stream, void* side_stream);
 
 /* Losses of Svae.training_step / validation_step (svae_model.py:171-182, 210-221): BCE-with-logits
  * (sum) of edge_scores against the parent flags x[..., C:], cross entropy (sum) of type_scores

@@ -227,3 +227,27 @@ def test_full_size_batch_is_the_sum_of_its_shards(cuda):
     assert abs(total - float(out['loss'])) <= 1e-5 * abs(total)
     for k, p in model.named_parameters():
         close_scaled(p.grad, whole[k], tol=3e-4, what=k)      # the gradient tolerance of every test here
+
+
+def test_one_stream_and_two_streams_agree_bit_for_bit(cuda):
+    """The weight-gradient products run on the library's side stream beside the through-time chain; on one
+    stream the same launches run in order.  Same kernels, same sums: identical gradients."""
+    from dvae_amd import svae as S
+    d, bidir, C, N = load_svae_case("svae_enas_val8_bidir")
+    model = build_svae(d, bidir, C, N, cuda)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.cat((torch.nn.functional.one_hot(torch.randint(0, C, (700, N - 1), generator=gen), C).float(),
+                   (torch.rand(700, N - 1, N, generator=gen) < 0.5).float()), dim=-1).to(cuda)
+    eps = torch.randn(700, 56, generator=gen).to(cuda)
+    grads = []
+    try:
+        for two in (True, False, True):
+            S.TWO_STREAMS = two
+            model.zero_grad()
+            model.training_step({'graph': x}, 0, eps=eps)['loss'].backward()
+            torch.cuda.synchronize()
+            grads.append([p.grad.clone() for p in model.parameters()])
+    finally:
+        S.TWO_STREAMS = True
+    for a, b, c in zip(*grads):
+        assert torch.equal(a, b) and torch.equal(a, c)
