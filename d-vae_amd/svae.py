@@ -57,17 +57,55 @@ def _dims(d0, B, T):
     return _lib.make_svae_dims(B, T, d0.C, d0.N, d0.H, d0.Z, d0.bidir)
 
 
+# raw forward / backward calls (no autograd): used by the Functions below and by Svae.loss_and_grad
+def _enc_fwd(d, x, P):
+    lib = load()
+    ws = torch.empty(lib.dvae_svae_enc_ws_bytes(ctypes.byref(d)), dtype=torch.uint8, device=x.device)
+    mu = torch.empty(d.B, d.Z, device=x.device)
+    logvar = torch.empty(d.B, d.Z, device=x.device)
+    check(lib.dvae_svae_enc_fwd(ctypes.byref(d), _ptr(x), _ptr(P), _ptr(ws), _ptr(mu), _ptr(logvar), _stream()))
+    return ws, mu, logvar
+
+
+def _enc_bwd(d, P, ws, d_mu, d_logvar, G, side):
+    check(load().dvae_svae_enc_bwd(ctypes.byref(d), _ptr(P), _ptr(ws), _ptr(d_mu), _ptr(d_logvar), _ptr(G), _stream(),
+                                   E._side(side)))
+
+
+def _dec_fwd(d, z, P):
+    lib = load()
+    ws = torch.empty(lib.dvae_svae_dec_ws_bytes(ctypes.byref(d)), dtype=torch.uint8, device=z.device)
+    ts = torch.empty(d.B, d.T, d.C, device=z.device)
+    es = torch.empty(d.B, d.T, d.N, device=z.device)
+    check(lib.dvae_svae_dec_fwd(ctypes.byref(d), _ptr(z), _ptr(P), _ptr(ws), _ptr(ts), _ptr(es), _stream()))
+    return ws, ts, es
+
+
+def _dec_bwd(d, P, ws, d_ts, d_es, G, side):
+    d_z = torch.empty(d.B, d.Z, device=P.device)
+    check(load().dvae_svae_dec_bwd(ctypes.byref(d), _ptr(P), _ptr(ws), _ptr(d_ts), _ptr(d_es), _ptr(G), _ptr(d_z),
+                                   _stream(), E._side(side)))
+    return d_z
+
+
+def _elbo(d, ts, es, x, mu, logvar, beta):
+    lib = load()
+    out4 = torch.empty(4, device=x.device)
+    part = torch.empty(lib.dvae_elbo_ws_bytes(d.B), dtype=torch.uint8, device=x.device)
+    grads = (torch.empty_like(ts), torch.empty_like(es), torch.empty_like(mu), torch.empty_like(logvar))
+    check(lib.dvae_svae_elbo(ctypes.byref(d), _ptr(ts), _ptr(es), _ptr(x), _ptr(mu), _ptr(logvar),
+                             ctypes.c_float(beta), _ptr(out4), _ptr(part), _ptr(grads[0]), _ptr(grads[1]),
+                             _ptr(grads[2]), _ptr(grads[3]), _stream()))
+    return out4, grads
+
+
 class _EncFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):
-        lib = load()
         B, T, _ = x.shape
         d = _dims(module._dims, B, T)
         P = module._pack.pack(d, params)
-        ws = torch.empty(lib.dvae_svae_enc_ws_bytes(ctypes.byref(d)), dtype=torch.uint8, device=x.device)
-        mu = torch.empty(B, d.Z, device=x.device)
-        logvar = torch.empty(B, d.Z, device=x.device)
-        check(lib.dvae_svae_enc_fwd(ctypes.byref(d), _ptr(x), _ptr(P), _ptr(ws), _ptr(mu), _ptr(logvar), _stream()))
+        ws, mu, logvar = _enc_fwd(d, x, P)
         ctx.d, ctx.P, ctx.ws, ctx.module, ctx.params = d, P, ws, module, params
         return mu, logvar
 
@@ -77,10 +115,7 @@ class _EncFn(torch.autograd.Function):
         G = torch.empty(pack.gfloats, dtype=torch.float32, device=ctx.P.device)
         cont = lambda t: None if t is None else t.contiguous()
         d_mu, d_logvar = cont(d_mu), cont(d_logvar)
-        run = lambda side: check(load().dvae_svae_enc_bwd(
-            ctypes.byref(ctx.d), _ptr(ctx.P), _ptr(ctx.ws), _ptr(d_mu), _ptr(d_logvar), _ptr(G), _stream(),
-            E._side(side)))
-        flat = _two_streams(pack, G, run)[0]
+        flat = _two_streams(pack, G, lambda side: _enc_bwd(ctx.d, ctx.P, ctx.ws, d_mu, d_logvar, G, side))[0]
         grads = pack.views(flat, ctx.params)
         ctx.ws = None
         return (None, None) + tuple(grads)
@@ -89,30 +124,19 @@ class _EncFn(torch.autograd.Function):
 class _DecFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, z, *params):
-        lib = load()
-        B = z.shape[0]
-        d = _dims(module._dims, B, module.max_seq_len - 1)
+        d = _dims(module._dims, z.shape[0], module.max_seq_len - 1)
         P = module._pack.pack(d, params)
-        ws = torch.empty(lib.dvae_svae_dec_ws_bytes(ctypes.byref(d)), dtype=torch.uint8, device=z.device)
-        ts = torch.empty(B, d.T, d.C, device=z.device)
-        es = torch.empty(B, d.T, d.N, device=z.device)
-        zc = _f32c(z)
-        check(lib.dvae_svae_dec_fwd(ctypes.byref(d), _ptr(zc), _ptr(P), _ptr(ws), _ptr(ts), _ptr(es), _stream()))
+        ws, ts, es = _dec_fwd(d, _f32c(z), P)
         ctx.d, ctx.P, ctx.ws, ctx.module, ctx.params = d, P, ws, module, params
         return ts, es
 
     @staticmethod
     def backward(ctx, d_ts, d_es):
         pack = ctx.module._pack
-        d = ctx.d
         G = torch.empty(pack.gfloats, dtype=torch.float32, device=ctx.P.device)
         cont = lambda t: None if t is None else t.contiguous()
         d_ts, d_es = cont(d_ts), cont(d_es)
-        d_z = torch.empty(d.B, d.Z, device=ctx.P.device)
-        run = lambda side: check(load().dvae_svae_dec_bwd(
-            ctypes.byref(d), _ptr(ctx.P), _ptr(ctx.ws), _ptr(d_ts), _ptr(d_es), _ptr(G), _ptr(d_z), _stream(),
-            E._side(side)))
-        flat = _two_streams(pack, G, run)[0]
+        flat, d_z = _two_streams(pack, G, lambda side: _dec_bwd(ctx.d, ctx.P, ctx.ws, d_ts, d_es, G, side))
         grads = pack.views(flat, ctx.params)
         ctx.ws = None
         return (None, d_z) + tuple(grads)
@@ -124,14 +148,7 @@ class _ElboFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, d, ts, es, x, mu, logvar, beta):
-        lib = load()
-        ts, es, mu, logvar = ts.contiguous(), es.contiguous(), mu.contiguous(), logvar.contiguous()
-        out4 = torch.empty(4, device=x.device)
-        part = torch.empty(lib.dvae_elbo_ws_bytes(d.B), dtype=torch.uint8, device=x.device)
-        grads = (torch.empty_like(ts), torch.empty_like(es), torch.empty_like(mu), torch.empty_like(logvar))
-        check(lib.dvae_svae_elbo(ctypes.byref(d), _ptr(ts), _ptr(es), _ptr(x), _ptr(mu), _ptr(logvar),
-                                 ctypes.c_float(beta), _ptr(out4), _ptr(part), _ptr(grads[0]), _ptr(grads[1]),
-                                 _ptr(grads[2]), _ptr(grads[3]), _stream()))
+        out4, grads = _elbo(d, ts.contiguous(), es.contiguous(), x, mu.contiguous(), logvar.contiguous(), beta)
         ctx.save_for_backward(*grads)
         ctx.beta = beta
         return out4
@@ -286,6 +303,67 @@ class Svae(nn.Module):
         with torch.no_grad():
             acc = self.compute_accuracy(es.detach(), ts.detach(), x, is_logits=True)
         return out4, acc
+
+    def loss_and_grad(self, batch, eps=None, beta=None, grad_sync=None):
+        """Forward + backward of training_step's loss without an autograd graph (an addition, as
+        ``Dvae.loss_and_grad``): same kernels, gradients written into two flat buffers whose views become
+        ``p.grad``.  ``grad_sync(flat)`` (optional, e.g. ``dp.make_grad_sync(dist)``) is queued on the side
+        stream as soon as a buffer is complete -- the decoder's while the encoder's backward still runs.
+        Returns the device tensor [edge_loss, vertex_loss, kl_loss, loss]."""
+        enc, dec = self.encoder, self.decoder
+        x = _f32c(batch["graph"])
+        E._require_cuda(x, "graph")
+        assert x.dim() == 3 and x.shape[2] == enc.inp_dim, 'expected [B, T, %d] strings' % enc.inp_dim
+        beta = self.beta if beta is None else beta
+        enc_p, dec_p = enc.hip_params(), dec.hip_params()
+        with torch.no_grad():
+            main = torch.cuda.current_stream()
+            side = E.side_stream(x.device)
+            de, dd = _dims(enc._dims, x.shape[0], x.shape[1]), _dims(dec._dims, x.shape[0], x.shape[1])
+            Pe = enc._pack.pack(de, enc_p)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):       # the decoder's weights are not needed before the encoder is through
+                Pd = dec._pack.pack(dd, dec_p)
+                pd_ready = torch.cuda.Event()
+                pd_ready.record(side)
+            key = tuple(p.data_ptr() for p in enc_p + dec_p)
+            if getattr(self, '_flat', None) is None or self._flat[0] != key:
+                self._flat = (key, torch.zeros(sum(p.numel() for p in enc_p), device=x.device),
+                              torch.zeros(sum(p.numel() for p in dec_p), device=x.device))
+            fe, fd = self._flat[1], self._flat[2]
+            ws_e, mu, logvar = _enc_fwd(de, x, Pe)
+            if eps is None:
+                eps = torch.randn_like(mu)
+            z = E.reparam_fwd(mu, logvar, _f32c(eps))
+            main.wait_event(pd_ready)
+            ws_d, ts, es = _dec_fwd(dd, z, Pd)
+            out4, (gt, ge, gmu, glv) = _elbo(dd, ts, es, x, mu, logvar, float(beta))
+            Gd = torch.empty(dec._pack.gfloats, dtype=torch.float32, device=x.device)
+            Ge = torch.empty(enc._pack.gfloats, dtype=torch.float32, device=x.device)
+            handles = []
+            side.wait_stream(main)
+            d_z = _dec_bwd(dd, Pd, ws_d, gt, ge, Gd, side)
+            with torch.cuda.stream(side):
+                dec._pack.unpack(Gd, fd)
+                if grad_sync is not None:
+                    handles.append(grad_sync(fd))
+            dmu, dlv = E.reparam_bwd(d_z, logvar, _f32c(eps))
+            gmu.add_(dmu)
+            glv.add_(dlv)
+            _enc_bwd(de, Pe, ws_e, gmu, glv, Ge, side)
+            with torch.cuda.stream(side):
+                enc._pack.unpack(Ge, fe)
+                if grad_sync is not None:
+                    handles.append(grad_sync(fe))
+            main.wait_stream(side)
+            for p, v in zip(enc_p, enc._pack.views(fe, enc_p)):
+                p.grad = v
+            for p, v in zip(dec_p, dec._pack.views(fd, dec_p)):
+                p.grad = v
+            for h in handles:
+                if h is not None:
+                    h.wait()
+        return out4
 
     def training_step(self, batch, batch_nb, eps=None):
         out4, acc = self._losses(batch, self.beta, eps)     # :182 uses self.beta

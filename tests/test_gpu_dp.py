@@ -81,12 +81,8 @@ def _svae_worker(rank, world, port, ret):
     eps = torch.randn(11, 56, generator=gen)                                   # drawn per GLOBAL string index
     full = {'graph': x.to(dev), 'eps': eps.to(dev)}
     mine = dp.shard_batch(full, rank, world)
-    out = model.training_step(mine, 0, eps=mine['eps'])
-    out['loss'].backward()
-    sync = dp.make_grad_sync(dist)
-    for p in model.parameters():                                               # the Trainer's rule: SUM all-reduce
-        sync(p.grad).wait()
-    loss = dp.allreduce_losses(dist, out['loss'].detach().reshape(1).clone())
+    out4 = model.loss_and_grad(mine, eps=mine['eps'], grad_sync=dp.make_grad_sync(dist))   # SUM all-reduce of two flat buffers
+    loss = dp.allreduce_losses(dist, out4.clone())[3:4]
     torch.cuda.synchronize()
     grads = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
     if rank == 0:

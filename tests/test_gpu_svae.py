@@ -251,3 +251,31 @@ def test_one_stream_and_two_streams_agree_bit_for_bit(cuda):
         S.TWO_STREAMS = True
     for a, b, c in zip(*grads):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("bidir", [False, True])
+def test_fused_step_equals_the_autograd_path(cuda, bidir):
+    """Svae.loss_and_grad (no autograd graph, gradients in two flat buffers) runs the same kernels as
+    training_step + backward: identical losses and gradients; the flat buffers hold every gradient once."""
+    import dvae_amd
+    torch.manual_seed(1)
+    model = dvae_amd.Svae(Namespace(dataset_file=None, bidirectional=bidir, beta=0.01)).to(cuda)
+    gen = torch.Generator().manual_seed(6)
+    x = torch.cat((torch.nn.functional.one_hot(torch.randint(0, 8, (130, 7), generator=gen), 8).float(),
+                   (torch.rand(130, 7, 8, generator=gen) < 0.5).float()), dim=-1).to(cuda)
+    eps = torch.randn(130, 56, generator=gen).to(cuda)
+    out = model.training_step({'graph': x}, 0, eps=eps)
+    out['loss'].backward()
+    want = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    out4 = model.loss_and_grad({'graph': x}, eps=eps)
+    torch.cuda.synchronize()
+    assert float(out4[3]) == float(out['loss'])
+    for p, w in zip(model.parameters(), want):
+        assert torch.equal(p.grad, w)
+    assert model._flat[1].numel() + model._flat[2].numel() == sum(p.numel() for p in model.parameters())
+    out4b = model.loss_and_grad({'graph': x}, eps=eps)          # buffers are reused, not accumulated into
+    torch.cuda.synchronize()
+    assert torch.equal(out4, out4b)
+    for p, w in zip(model.parameters(), want):
+        assert torch.equal(p.grad, w)

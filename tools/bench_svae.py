@@ -62,6 +62,9 @@ for bidir in (False, True):
         out = m.training_step({'graph': xd}, 0)
         out['loss'].backward(); opt.step()
     t_hip = timed(hip_step)
+    def fused_step():
+        m.loss_and_grad({'graph': xd}); opt.step()
+    t_fused = timed(fused_step)
     tm = TorchSvae(bidir).to(dev)
     topt = torch.optim.Adam(tm.parameters(), lr=1e-3)
     def torch_step():
@@ -69,6 +72,7 @@ for bidir in (False, True):
         tm.loss(xd).backward(); topt.step()
     t_torch = timed(torch_step)
     res['bidir' if bidir else 'uni'] = {'hip_ms': round(t_hip, 3), 'strings_per_s': round(B / t_hip * 1e3),
+                                        'hip_fused_step_ms': round(t_fused, 3),
                                         'torch_miopen_ms': round(t_torch, 3), 'speedup': round(t_torch / t_hip, 2)}
     print(res, flush=True)
 
