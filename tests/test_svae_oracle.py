@@ -79,3 +79,40 @@ def test_svae_mirror_has_the_reference_surface():
     assert m.decoder.add_edges[2].weight.shape == (8, 501)
     with pytest.raises(Exception):           # no CPU fallback
         m(torch.zeros(2, 7, 16))
+
+
+def test_svae_abi_host_side():
+    """dims validation, parameter counts and the pack table (host-only entry points: no GPU needed)."""
+    import ctypes
+    import dvae_amd
+    from dvae_amd import _lib
+    lib = _lib.load()
+    for bad in (dict(C=33), dict(N=0), dict(T=0), dict(H=4096), dict(B=0)):
+        kw = dict(B=4, T=7, C=8, N=8, H=501, Z=56, bidir=1)
+        kw.update(bad)
+        with pytest.raises(_lib.DvaeError):
+            _lib.make_svae_dims(**kw)
+    d = _lib.make_svae_dims(4, 7, 8, 8, 501, 56, True)
+    assert (d.I, d.IP, d.HP, d.ZP) == (16, 32, 512, 64)
+    assert lib.dvae_svae_enc_param_count(ctypes.byref(d)) == 14 and lib.dvae_svae_dec_param_count(ctypes.byref(d)) == 14
+    d.bidir = 0
+    assert lib.dvae_svae_enc_param_count(ctypes.byref(d)) == 8
+    HP, IP, ZP = 512, 32, 64
+    gru = lambda kp: 3 * HP * kp + 3 * HP * HP + 6 * HP
+    assert lib.dvae_svae_enc_param_floats(ctypes.byref(d)) == gru(IP) + 2 * ZP * HP + 2 * ZP
+    assert lib.dvae_svae_dec_param_floats(ctypes.byref(d)) == HP * ZP + HP + gru(HP) + 2 * HP * HP + 2 * HP + 2 * (32 * HP + 32)
+    # the table covers every element of every tensor exactly once
+    m = dvae_amd.Svae(Namespace(dataset_file=None, bidirectional=True))
+    for mod, fn, kind in ((m.encoder, lib.dvae_svae_enc_pack_table, 1), (m.decoder, lib.dvae_svae_dec_pack_table, 0)):
+        ps = mod.hip_params()
+        dd = _lib.make_svae_dims(1, 1, 8, 8, 501, 56, kind)
+        raw = np.array([1 << 20] * len(ps), dtype=np.uint64)          # fake addresses: the table is built on the host
+        offs = np.cumsum([0] + [p.numel() for p in ps])[:-1].astype(np.int64)
+        host = (_lib.PackEntry * 256)()
+        n = fn(ctypes.byref(dd), ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(offs.ctypes.data),
+               ctypes.cast(host, ctypes.c_void_p), 256)
+        assert n > 0
+        assert sum(host[i].rows * host[i].cols for i in range(n)) == sum(p.numel() for p in ps)
+        small = (_lib.PackEntry * 4)()
+        assert fn(ctypes.byref(dd), ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(offs.ctypes.data),
+                  ctypes.cast(small, ctypes.c_void_p), 4) < 0
