@@ -42,19 +42,15 @@ def test_hip_matches_reference(cuda, name):
     check_grads_against_golden([(k, p.grad) for k, p in model.named_parameters()], d)
 
 
-@pytest.mark.parametrize("B,C,N,H,bidir", [(64, 8, 8, 501, True), (33, 6, 12, 200, False), (5, 10, 10, 64, True),
-                                           (1, 8, 2, 501, True), (300, 8, 8, 128, False)])
-def test_hip_matches_oracle(cuda, B, C, N, H, bidir):
-    """Every output and every gradient against the oracle, including odd sizes (one string, one step,
-    hidden widths that are / are not multiples of 64)."""
+def _against_oracle(cuda, B, C, N, H, bidir, Z=56, wseed=17):
     import dvae_amd
     from dvae_amd import svae as S
     from oracle import svae_ref as O
     torch.manual_seed(3)
     model = dvae_amd.Svae(Namespace(dataset_file=None, bidirectional=bidir, num_classes=C, max_seq=N))
-    model.encoder = S.Encoder(C, N, hidden_size=H, bidir=bidir)
-    model.decoder = S.Decoder(C, N, hidden_size=H)
-    fill_weights(model, 17)
+    model.encoder = S.Encoder(C, N, hidden_size=H, latent_dim=Z, bidir=bidir)
+    model.decoder = S.Decoder(C, N, hidden_size=H, latent_dim=Z)
+    fill_weights(model, wseed)
     model.to(cuda)
     T = N - 1
     sd0 = oracle_sd(model)
@@ -62,7 +58,7 @@ def test_hip_matches_oracle(cuda, B, C, N, H, bidir):
         gen = torch.Generator().manual_seed(1000 * B + seed)
         x = torch.cat((torch.nn.functional.one_hot(torch.randint(0, C, (B, T), generator=gen), C).float(),
                        (torch.rand(B, T, N, generator=gen) < 0.4).float()), dim=-1)
-        eps = torch.randn(B, 56, generator=gen)
+        eps = torch.randn(B, Z, generator=gen)
         with torch.no_grad():
             mu0, lv0 = O.encoder(sd0, x, bidir)
             if O.relu_margin(sd0, eps * torch.exp(0.5 * lv0) + mu0, T) > 1e-6:
@@ -74,7 +70,8 @@ def test_hip_matches_oracle(cuda, B, C, N, H, bidir):
     ref[0].backward()
     out = model.training_step({'graph': x.to(cuda)}, 0, eps=eps.to(cuda))
     got = [float(out['log'][k]) for k in ('train/edge_loss', 'train/vertex_loss', 'train/kl_loss', 'train/loss')]
-    np.testing.assert_allclose(got, [float(ref[1]), float(ref[2]), float(ref[3]), float(ref[0])], rtol=1e-4)
+    np.testing.assert_allclose(got, [float(ref[1].detach()), float(ref[2].detach()), float(ref[3].detach()),
+                                     float(ref[0].detach())], rtol=1e-4)
     out['loss'].backward()
     for k, p in model.named_parameters():
         close_scaled(p.grad, sd[k].grad, tol=3e-4, what=k)
@@ -82,6 +79,28 @@ def test_hip_matches_oracle(cuda, B, C, N, H, bidir):
         ts, es, mu, lv = model(x.to(cuda), eps=eps.to(cuda))
     for a, b, what in ((ts, ref[6], "type scores"), (es, ref[7], "edge scores"), (mu, ref[4], "mu"), (lv, ref[5], "logvar")):
         close_scaled(a, b, what=what)
+
+
+@pytest.mark.parametrize("B,C,N,H,bidir", [(64, 8, 8, 501, True), (33, 6, 12, 200, False), (5, 10, 10, 64, True),
+                                           (1, 8, 2, 501, True), (300, 8, 8, 128, False)])
+def test_hip_matches_oracle(cuda, B, C, N, H, bidir):
+    """Every output and every gradient against the oracle, including odd sizes (one string, one step,
+    hidden widths that are / are not multiples of 64)."""
+    _against_oracle(cuda, B, C, N, H, bidir)
+
+
+def test_random_configurations_against_oracle(cuda):
+    """Seeded sweep over batch size, type count, string length, hidden and latent widths, direction."""
+    import random
+    rng = random.Random(20240611)
+    for i in range(12):
+        B, C, N = rng.randint(1, 90), rng.randint(2, 14), rng.randint(2, 14)
+        H, Z = rng.choice([40, 64, 100, 128, 200, 333]), rng.choice([8, 56, 64, 70])
+        bidir = rng.random() < 0.5
+        try:
+            _against_oracle(cuda, B, C, N, H, bidir, Z=Z, wseed=100 + i)
+        except AssertionError as e:
+            raise AssertionError("configuration %d (B=%d C=%d N=%d H=%d Z=%d bidir=%s): %s" % (i, B, C, N, H, Z, bidir, e))
 
 
 def test_gradients_through_the_pieces(cuda):
