@@ -48,6 +48,10 @@ void dvae_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------
 // internal launchers shared between translation units
 // ---------------------------------------------------------------------------
+// split-K partial sums left for the consumer kernel to add up (GemmDesc::partials): slab s of the product is
+// slab + s * stride, [M][N] with leading dimension N; slab == NULL: the product was written to C whole
+struct GemmPartials { const float* slab; int splits; long long stride; };
+
 struct GemmDesc {
   const float* A; int lda; int a_kmajor;   // a_kmajor=0: A[M][K]; 1: A[K][M]
   const float* B; int ldb; int b_kmajor;   // b_kmajor=0: B[N][K]; 1: B[K][N]
@@ -63,6 +67,9 @@ struct GemmDesc {
                        // writes C row row_map[m] -- a product over a scattered subset of rows
   const int* k_map;    // optional (both operands k-major): reduction index k reads memory row k_map[k]
                        // of A and of B -- a weight gradient summed over a scattered subset of rows
+  GemmPartials* partials;   // optional out (no bias / relu / accumulate): when the product is split over K, skip
+                            // the combine launch and describe the slabs here; the consumer sums them in slab
+                            // order (the combine's order) before the next product on this stream reuses ws
 };
 // C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);

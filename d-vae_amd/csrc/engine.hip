@@ -196,8 +196,9 @@ struct G {
   float* ws; hipStream_t st; int prio = 0; int bulk = 0;
   // Y[M][N] (+)= X[M][K] W[N][K]^T + bias
   int nt(const float* X, int ldx, const float* W, int ldw, float* Y, int ldy, int M, int N, int K,
-         const float* bias = nullptr, int relu = 0, int acc = 0, const int* rows = nullptr) const {
-    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio, bulk, rows, nullptr};
+         const float* bias = nullptr, int relu = 0, int acc = 0, const int* rows = nullptr,
+         GemmPartials* parts = nullptr) const {
+    GemmDesc d{X, ldx, 0, W, ldw, 0, Y, ldy, M, N, K, bias, relu, acc, prio, bulk, rows, nullptr, parts};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dX[M][N] (+)= dY[M][K] W[K][N]
@@ -313,10 +314,13 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   // dvae_level_tune / DVAE_FUSED_GRU=1.
   const bool fused_gru = g_level_cfg.fused_gru != 0;
   const int fused_gm_min = g_level_cfg.fused_gm_min_rows;
+  static const bool fold_partials = getenv("DVAE_NO_FOLD") == nullptr;   // A-B tests: combine launch instead
   auto gru_rows = [&](int p0, int p1) -> int {
     if (fused_gru) return k_level_gru_fwd(S, p0, p1, b, x, d.N, d.C, w.gru, HP, g.prio, st);
-    DVAE_TRY(g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0, 3 * HP, HP));
-    return k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st);
+    GemmPartials parts{nullptr, 1, 0};   // a small level's split-K slabs go to the gate kernel as they are
+    DVAE_TRY(g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0, 3 * HP, HP,
+                  nullptr, 0, 0, nullptr, fold_partials ? &parts : nullptr));
+    return k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st, &parts);
   };
   if (d.mod == 1) {
     // gate/map depends on node types only: no inter-node dependency, one "level"
@@ -358,9 +362,11 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       if (fused_gm_min >= 0 && ne - ns >= fused_gm_min) {
         DVAE_TRY(k_level_gm_fwd(S, ns, ne, b, w.gm, w.gm + (size_t)2 * HP * HP, HP, g.prio, st));
       } else {
+        // a small level's product is split over K: its slabs go to the gate/map kernel as they are
+        GemmPartials parts{nullptr, 1, 0};
         DVAE_TRY(g.nt(b.Hn + (size_t)ns * HP, HP, w.gm, HP, b.GMP + (size_t)ns * 2 * HP, 2 * HP, ne - ns, 2 * HP,
-                      HP));
-        DVAE_TRY(k_gm_fwd(S, ns, ne, b, w.gm + (size_t)2 * HP * HP, HP, st));
+                      HP, nullptr, 0, 0, nullptr, fold_partials ? &parts : nullptr));
+        DVAE_TRY(k_gm_fwd(S, ns, ne, b, w.gm + (size_t)2 * HP * HP, HP, st, &parts));
       }
       // the hidden product of this level's gated states, once per node
       if (pg)

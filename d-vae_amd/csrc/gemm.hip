@@ -467,7 +467,12 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
                      0, stream, p);
   prof_end(pr, stream);
   DVAE_LAUNCH_CHECK();
-  if (splits > 1) {
+  if (d.partials) {
+    d.partials->slab = splits > 1 ? ws : nullptr;
+    d.partials->splits = splits;
+    d.partials->stride = (long long)d.M * d.N;
+  }
+  if (splits > 1 && !d.partials) {
     const long long total = (long long)d.M * (d.N / 4);
     const int grid = (int)min((long long)2048, (total + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, ws, splits,
@@ -490,6 +495,7 @@ extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0) return DVAE_OK;
   DVAE_REQUIRE(d.K > 0, "gemm: K must be positive");
+  DVAE_REQUIRE(!d.partials || (!d.bias && !d.relu && !d.accumulate), "gemm: partial sums carry no epilogue");
   DVAE_REQUIRE(!d.row_map || !d.a_kmajor, "gemm: a row map needs an m-major A");
   if (d.k_map) {
     // gathered reduction rows: the weight-gradient shape only (TN, 128x128 tiles, split K)
@@ -547,7 +553,7 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
 extern "C" int dvae_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
                              int b_kmajor, float* C, int ldc, int M, int N, int K, const float* bias,
                              int relu, int accumulate, float* ws, size_t ws_bytes, void* stream) {
-  GemmDesc d;
+  GemmDesc d{};
   d.A = A; d.lda = lda; d.a_kmajor = a_kmajor;
   d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
   d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
@@ -561,7 +567,7 @@ extern "C" int dvae_gemm_f32_mapped(const float* A, int lda, int a_kmajor, const
                                     const int* row_map, const int* k_map, float* ws, size_t ws_bytes,
                                     void* stream) {
   DVAE_REQUIRE(!(row_map && k_map), "gemm: one map at a time");
-  GemmDesc d;
+  GemmDesc d{};
   d.A = A; d.lda = lda; d.a_kmajor = a_kmajor;
   d.B = B; d.ldb = ldb; d.b_kmajor = b_kmajor;
   d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;

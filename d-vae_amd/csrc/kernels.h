@@ -55,9 +55,12 @@ int k_prefix_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, cons
 int k_dgm_gather(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 // ... and, once DGM is complete, through g*m:  GMP <- (dGM*m*g*(1-g), dGM*g)
 int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
+// parts: the hidden product of rows [p0,p1) as split-K slabs (GemmDesc::partials) instead of whole in GH
 int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, const float* x, int N, int C,
-              const GruW& w, int HP, hipStream_t st);
-int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st);
+              const GruW& w, int HP, hipStream_t st, const GemmPartials* parts = nullptr);
+// parts: the gate/map product as split-K slabs (GemmDesc::partials) instead of whole in GMP
+int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st,
+             const GemmPartials* parts = nullptr);
 int k_gm_bn_fwd(const SchedDir& S, int R, const SweepBufs& b, const float* x, int N, int C,
                 const float* WgmT, const float* bgm, int HP, hipStream_t st);
 // fused level steps (level.hip): hidden GEMM + GRU gates for prefix/node rows [p0,p1) whose

@@ -87,7 +87,7 @@ __global__ void agg_fwd_kernel(SchedDir S, int R, int ns, int ne, int prefix, co
 __global__ void gru_fwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, int no_gh, float* __restrict__ GH,
                                const float* __restrict__ AGG, float* __restrict__ GHN,
                                float* __restrict__ HV, float* __restrict__ Hn,
-                               const float* __restrict__ x, int N, int C, GruW w, int HP) {
+                               const float* __restrict__ x, int N, int C, GruW w, int HP, GemmPartials parts) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(p1 - p0) * HP4;
   ITEM_LOOP(total) {
@@ -111,9 +111,21 @@ __global__ void gru_fwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, in
     float4 ghr = ld4(w.bhh + j), ghz = ld4(w.bhh + HP + j), ghn = ld4(w.bhh + 2 * HP + j);
     float4 a = zero4();
     if (!no_gh) {
-      ghr = add4(ghr, ld4(gh + j));
-      ghz = add4(ghz, ld4(gh + HP + j));
-      ghn = add4(ghn, ld4(gh + 2 * HP + j));
+      if (parts.slab) {   // the hidden product arrives as split-K slabs: add them up in slab order
+        const float* sp = parts.slab + (size_t)(p - p0) * 3 * HP + j;
+        float4 sr = zero4(), sz = zero4(), sn = zero4();
+        for (int k = 0; k < parts.splits; ++k) {
+          const float* sk = sp + (size_t)k * parts.stride;
+          sr = add4(sr, ld4(sk));
+          sz = add4(sz, ld4(sk + HP));
+          sn = add4(sn, ld4(sk + 2 * HP));
+        }
+        ghr = add4(ghr, sr); ghz = add4(ghz, sz); ghn = add4(ghn, sn);
+      } else {
+        ghr = add4(ghr, ld4(gh + j));
+        ghz = add4(ghz, ld4(gh + HP + j));
+        ghn = add4(ghn, ld4(gh + 2 * HP + j));
+      }
       a = ld4(AGG + (size_t)p * HP + j);
     }
     float4 rr, zz, nn, hh;
@@ -268,15 +280,28 @@ __global__ void type_gru_bwd_kernel(int C, GruW w, const float* __restrict__ T, 
 // gate/map epilogue, mod None: GMP holds h.[Wg;Wm][:, :H]^T; the position one-hot
 // columns and the biases come in as posb[i] (dvae_model.py:71-79)
 __global__ void gm_fwd_kernel(SchedDir S, int ns, int ne, float* __restrict__ GMP,
-                              const float* __restrict__ posb, float* __restrict__ GM, int HP) {
+                              const float* __restrict__ posb, float* __restrict__ GM, int HP,
+                              GemmPartials parts) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(ne - ns) * HP4;
   ITEM_LOOP(total) {
     const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
     const int i = S.row_node[r];
     float* gp = GMP + (size_t)r * 2 * HP;
-    const float4 gpre = add4(ld4(gp + j), ld4(posb + (size_t)i * 2 * HP + j));
-    const float4 m = add4(ld4(gp + HP + j), ld4(posb + (size_t)i * 2 * HP + HP + j));
+    float4 pg, pm;
+    if (parts.slab) {   // the product arrives as split-K slabs: add them up in slab order
+      const float* sp = parts.slab + (size_t)(r - ns) * 2 * HP + j;
+      pg = zero4(); pm = zero4();
+      for (int k = 0; k < parts.splits; ++k) {
+        pg = add4(pg, ld4(sp + (size_t)k * parts.stride));
+        pm = add4(pm, ld4(sp + (size_t)k * parts.stride + HP));
+      }
+    } else {
+      pg = ld4(gp + j);
+      pm = ld4(gp + HP + j);
+    }
+    const float4 gpre = add4(pg, ld4(posb + (size_t)i * 2 * HP + j));
+    const float4 m = add4(pm, ld4(posb + (size_t)i * 2 * HP + HP + j));
     const float4 g = make_float4(sigm(gpre.x), sigm(gpre.y), sigm(gpre.z), sigm(gpre.w));
     st4(gp + j, g);
     st4(gp + HP + j, m);
@@ -1154,10 +1179,11 @@ int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st) {
 }
 
 int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, const float* x, int N, int C,
-              const GruW& w, int HP, hipStream_t st) {
+              const GruW& w, int HP, hipStream_t st, const GemmPartials* parts) {
   if (p1 <= p0) return DVAE_OK;
   hipLaunchKernelGGL(gru_fwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, b.R, p0, p1,
-                     b.prefix, no_gh, b.GH, b.AGG, b.GHN, b.HV, b.Hn, x, N, C, w, HP);
+                     b.prefix, no_gh, b.GH, b.AGG, b.GHN, b.HV, b.Hn, x, N, C, w, HP,
+                     parts ? *parts : GemmPartials{nullptr, 1, 0});
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
@@ -1175,10 +1201,11 @@ int k_type_gru_bwd(int C, const GruW& w, const float* T, float* TG, float* TGN, 
   return DVAE_OK;
 }
 
-int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st) {
+int k_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* posb, int HP, hipStream_t st,
+             const GemmPartials* parts) {
   if (ne <= ns) return DVAE_OK;
   hipLaunchKernelGGL(gm_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, ns, ne,
-                     b.GMP, posb, b.GM, HP);
+                     b.GMP, posb, b.GM, HP, parts ? *parts : GemmPartials{nullptr, 1, 0});
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
