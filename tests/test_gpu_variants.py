@@ -201,3 +201,40 @@ def test_early_weight_gradient_chunk(cuda, bidir):
         rel = float((o[1] - ref[1]).norm() / ref[1].norm())
         assert rel <= 1e-5, "gradients: relative L2 error %.3e" % rel
         close_scaled(o[1], ref[1], tol=1e-4, what="gradients")
+
+
+def test_folded_splitk_combine_is_bit_identical(cuda, tmp_path):
+    """Small levels: the split-K slabs of the gate/map and hidden products are summed by the consumer kernel
+    (default) or by a combine launch (DVAE_NO_FOLD=1, read once per process): same sums in the same order,
+    so losses and gradients agree bit for bit.  The other mode runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "run.py"
+    script.write_text('''
+import sys, torch
+from argparse import Namespace
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import dvae_amd
+from helpers import fill_weights
+dev = torch.device("cuda")
+out = {}
+for bidir in (False, True):
+    model = fill_weights(dvae_amd.Dvae(Namespace(dataset_file=None, mod=None, bidirectional=bidir)), 3).to(dev)
+    g, x = dvae_amd.synth.enas_like(300, 5)
+    eps = torch.randn(300, 56, generator=torch.Generator().manual_seed(1))
+    o4 = model.loss_and_grad({"graph": g.to(dev), "node_encoding": x.to(dev)}, eps=eps.to(dev))
+    torch.cuda.synchronize()
+    out[bidir] = (o4.cpu(), [p.grad.cpu().clone() for p in model.parameters()])
+torch.save(out, sys.argv[1])
+''' % (root, os.path.join(root, "tests")))
+    res = {}
+    for tag, env in (("fold", {}), ("nofold", {"DVAE_NO_FOLD": "1"})):
+        path = str(tmp_path / (tag + ".pt"))
+        subprocess.run([sys.executable, str(script), path], check=True, env=dict(os.environ, **env), timeout=300)
+        res[tag] = torch.load(path, weights_only=True)
+    for bidir in (False, True):
+        a, b = res["fold"][bidir], res["nofold"][bidir]
+        assert torch.equal(a[0], b[0])
+        assert all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
