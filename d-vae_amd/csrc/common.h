@@ -67,9 +67,10 @@ struct GemmDesc {
                        // writes C row row_map[m] -- a product over a scattered subset of rows
   const int* k_map;    // optional (both operands k-major): reduction index k reads memory row k_map[k]
                        // of A and of B -- a weight gradient summed over a scattered subset of rows
-  GemmPartials* partials;   // optional out (no bias / relu / accumulate): when the product is split over K, skip
-                            // the combine launch and describe the slabs here; the consumer sums them in slab
-                            // order (the combine's order) before the next product on this stream reuses ws
+  GemmPartials* partials;   // optional out (no bias / relu): when the product is split over K, skip the combine
+                            // launch and describe the slabs here; the consumer sums them in slab order (the
+                            // combine's order), then adds what C holds if `accumulate` -- C is left untouched --
+                            // before the next product on this stream reuses ws
 };
 // C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);

@@ -203,8 +203,8 @@ struct G {
   }
   // dX[M][N] (+)= dY[M][K] W[K][N]
   int nn(const float* dY, int ldy, const float* W, int ldw, float* dX, int ldx, int M, int N, int K,
-         int acc = 0, const int* rows = nullptr) const {
-    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio, bulk, rows, nullptr};
+         int acc = 0, const int* rows = nullptr, GemmPartials* parts = nullptr) const {
+    GemmDesc d{dY, ldy, 0, W, ldw, 1, dX, ldx, M, N, K, nullptr, 0, acc, prio, bulk, rows, nullptr, parts};
     return gemm_f32(d, ws, GEMM_WS_BYTES, st);
   }
   // dW[M][N] (+)= dY[K][M]^T X[K][N]   (K = rows)
@@ -405,28 +405,31 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   }
   float* dtarget = b.prefix ? b.DHn : b.DH;
   const bool pg = node_hidden(d, b);
+  static const bool fold_partials_bwd = getenv("DVAE_NO_FOLD") == nullptr;   // A-B tests: combine launch instead
   for (int L = lv.nlev - 1; L >= 0; --L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
+    GemmPartials gparts{nullptr, 1, 0};   // gate/map input gradient of this level, when left as split-K slabs
     if (L + 1 < lv.nlev) {
       if (pg) {
         // dL/dGM[u] = (direct gradients of the rows that hold u) + (their dgh, summed).Whh: the hidden
         // product's input gradient once per node instead of once per prefix row
         DVAE_TRY(k_dgm_gather(S, ns, ne, b, HP, st));
+        GemmPartials parts{nullptr, 1, 0};   // a small level's split-K slabs are added by the consumer
         DVAE_TRY(g.nn(b.PG + (size_t)ns * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DGM + (size_t)ns * HP, HP, ne - ns, HP,
-                      3 * HP, 1));
-        DVAE_TRY(k_gm_bwd_apply(ns, ne, b, HP, st));
+                      3 * HP, 1, nullptr, fold_partials_bwd ? &parts : nullptr));
+        DVAE_TRY(k_gm_bwd_apply(ns, ne, b, HP, st, &parts));
       } else {
         DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
       }
       DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
-                    2 * HP, 1));
+                    2 * HP, 1, nullptr, fold_partials_bwd ? &gparts : nullptr));
     }
     if (L == 0) {
-      DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st));
+      DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st, &gparts, ns));
       if (seeded) DVAE_TRY(dagg_gemm(ns, ne));      // only node 0's h_in = h0 needs it
     } else {
       const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
-      DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st));
+      DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st, &gparts, ns));
       if (!pg) DVAE_TRY(dagg_gemm(p0, p1));
     }
     if (after_level) DVAE_TRY(after_level(L));   // levels >= L are final from here on

@@ -495,7 +495,7 @@ extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0) return DVAE_OK;
   DVAE_REQUIRE(d.K > 0, "gemm: K must be positive");
-  DVAE_REQUIRE(!d.partials || (!d.bias && !d.relu && !d.accumulate), "gemm: partial sums carry no epilogue");
+  DVAE_REQUIRE(!d.partials || (!d.bias && !d.relu), "gemm: partial sums carry no bias / relu");
   DVAE_REQUIRE(!d.row_map || !d.a_kmajor, "gemm: a row map needs an m-major A");
   if (d.k_map) {
     // gathered reduction rows: the weight-gradient shape only (TN, 128x128 tiles, split K)

@@ -54,7 +54,8 @@ int k_prefix_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, cons
 // prefix sweeps with PG: DGM[u] = sum of DH over the consumer rows that hold u, PG[u] = the same sum of dgh (GH)
 int k_dgm_gather(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 // ... and, once DGM is complete, through g*m:  GMP <- (dGM*m*g*(1-g), dGM*g)
-int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
+// parts: the hidden part of DGM as split-K slabs (GemmDesc::partials) still to be added to the direct part
+int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st, const GemmPartials* parts = nullptr);
 // parts: the hidden product of rows [p0,p1) as split-K slabs (GemmDesc::partials) instead of whole in GH
 int k_gru_fwd(const SchedDir& S, int p0, int p1, int no_gh, const SweepBufs& b, const float* x, int N, int C,
               const GruW& w, int HP, hipStream_t st, const GemmPartials* parts = nullptr);
@@ -71,7 +72,10 @@ int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const 
                    int HP, int prio, hipStream_t st);
 // with_gm_grad=0 (mod bn): only gathers dGM into GMP[:, :HP] scaled for the weight grads
 int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
-int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st);
+// parts: the gate/map input gradient of node rows [parts_row0, ..) as split-K slabs (GemmDesc::partials),
+// still to be added to the table that product accumulates into (DH, or DHn for prefix sweeps)
+int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st,
+              const GemmPartials* parts = nullptr, int parts_row0 = 0);
 // one-hot side tables for the skinny weight gradients (see layout.h)
 int k_build_xp(const SchedDir& S, int prefix, int rows, const float* x, int N, int C, float* XP, hipStream_t st);
 int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_t st);

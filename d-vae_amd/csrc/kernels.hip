@@ -392,12 +392,19 @@ __global__ void dgm_gather_kernel(SchedDir S, int ns, int ne, const float* __res
   }
 }
 
-__global__ void gm_bwd_apply_kernel(int ns, int ne, const float* __restrict__ DGM, float* __restrict__ GMP, int HP) {
+__global__ void gm_bwd_apply_kernel(int ns, int ne, const float* __restrict__ DGM, float* __restrict__ GMP, int HP,
+                                    GemmPartials parts) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(ne - ns) * HP4;
   ITEM_LOOP(total) {
     const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
-    const float4 d = ld4(DGM + (size_t)r * HP + j);
+    float4 d = ld4(DGM + (size_t)r * HP + j);
+    if (parts.slab) {   // the hidden part arrives as split-K slabs: (their sum, in slab order) + the direct part
+      const float* sp = parts.slab + (size_t)(r - ns) * HP + j;
+      float4 s = zero4();
+      for (int k = 0; k < parts.splits; ++k) s = add4(s, ld4(sp + (size_t)k * parts.stride));
+      d = add4(s, d);
+    }
     float* gp = GMP + (size_t)r * 2 * HP;
     const float4 g = ld4(gp + j), m = ld4(gp + HP + j);
     st4(gp + j, make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
@@ -410,15 +417,33 @@ __global__ void gm_bwd_apply_kernel(int ns, int ne, const float* __restrict__ DG
 // GHN -> dn_pre (so d(gi) = (GH_r, GH_z, GHN)); DH -> dh*z (direct path to h_in)
 __global__ void gru_bwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, float* __restrict__ GH,
                                float* __restrict__ GHN, const float* __restrict__ AGG,
-                               float* __restrict__ DH, const float* __restrict__ DHn, int HP) {
+                               float* __restrict__ DH, const float* __restrict__ DHn, int HP,
+                               GemmPartials parts, int parts_row0) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(p1 - p0) * HP4;
   ITEM_LOOP(total) {
     const int p = p0 + (int)(it / HP4), j = (int)(it % HP4) * 4;
     float4 dh = ld4(DH + (size_t)p * HP + j);
+    // parts: the gate/map input gradient of node rows [parts_row0, ..) still as split-K slabs; it belongs to
+    // the table the product accumulates into (DH of the node row, or DHn for prefix sweeps) and is added
+    // first, as the combine launch would have
     if (prefix && DHn) {
       const int r = S.prow_node[p];
-      if (p == final_prow(S, R, r)) dh = add4(dh, ld4(DHn + (size_t)r * HP + j));
+      if (p == final_prow(S, R, r)) {
+        float4 t = ld4(DHn + (size_t)r * HP + j);
+        if (parts.slab) {
+          const float* sp = parts.slab + (size_t)(r - parts_row0) * HP + j;
+          float4 s = zero4();
+          for (int k = 0; k < parts.splits; ++k) s = add4(s, ld4(sp + (size_t)k * parts.stride));
+          t = add4(s, t);
+        }
+        dh = add4(dh, t);
+      }
+    } else if (!prefix && parts.slab) {
+      const float* sp = parts.slab + (size_t)(p - parts_row0) * HP + j;
+      float4 s = zero4();
+      for (int k = 0; k < parts.splits; ++k) s = add4(s, ld4(sp + (size_t)k * parts.stride));
+      dh = add4(s, dh);
     }
     float* gh = GH + (size_t)p * 3 * HP;
     const float4 rr = ld4(gh + j), zz = ld4(gh + HP + j), nn = ld4(gh + 2 * HP + j);
@@ -1170,10 +1195,11 @@ int k_dgm_gather(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, 
   return DVAE_OK;
 }
 
-int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st) {
+int k_gm_bwd_apply(int ns, int ne, const SweepBufs& b, int HP, hipStream_t st, const GemmPartials* parts) {
   if (ne <= ns) return DVAE_OK;
   hipLaunchKernelGGL(gm_bwd_apply_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, ns, ne, b.DGM,
-                     b.GMP, HP);
+                     b.GMP, HP,
+                     parts ? *parts : GemmPartials{nullptr, 1, 0});
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
@@ -1227,10 +1253,12 @@ int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hip
   return DVAE_OK;
 }
 
-int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st) {
+int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st, const GemmPartials* parts,
+              int parts_row0) {
   if (p1 <= p0) return DVAE_OK;
   hipLaunchKernelGGL(gru_bwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, b.R, p0, p1,
-                     b.prefix, b.GH, b.GHN, b.AGG, b.DH, b.DHn, HP);
+                     b.prefix, b.GH, b.GHN, b.AGG, b.DH, b.DHn, HP, parts ? *parts : GemmPartials{nullptr, 1, 0},
+                     parts_row0);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
