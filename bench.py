@@ -3,18 +3,26 @@
 encode, reparameterise, teacher-forced decode, ELBO, backward, gradient
 all-reduce, Adam) on ENAS-like 8-node DAGs, hs=501, nz=56, global batch 4096.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config headline|c1|c2|c3|c4|c5]
 
-For N > 1 the driver launches one rank per GPU through torch.distributed.run
-(RCCL); rank 0 prints ONE JSON line.  Every step sees a different pre-generated
-batch (already resident in HBM), so the schedule build is inside the timed
-region, as it would be in training.
+N > 1: one rank per GPU over RCCL.  Either the caller wraps this file in
+torch.distributed.run (WORLD_SIZE is then set), or -- when WORLD_SIZE is unset --
+this process starts the N ranks itself, as children, BEFORE it touches the GPU, and
+exits with their status (the reference's analogue is `Trainer(gpus=...)`, train.py:46).
+Rank 0 prints ONE JSON line.  Every step sees a different pre-generated batch (already
+resident in HBM), so the schedule build is inside the timed region, as it would be in
+training.
+
+--config selects BASELINE.json's other configurations; the default is
+the configuration the metric is quoted on.
 """
 import argparse
 import ctypes
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from argparse import Namespace
@@ -24,68 +32,240 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H, Z, N, C = 501, 56, 8, 8
+H, Z = 501, 56
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E
 PROF_EVERY = 4                   # timed steps between two steps whose GEMM launches carry HIP events
 
+# BASELINE.json `configs` (c1..c5) + the headline shape of `metric`
+CONFIGS = {
+    "headline": dict(kind="train", mod=None, bidir=False, N=8, C=8, B=4096,
+                     workload="ENAS-like 8-node DAGs (chain + p=1/3), nvt=8, hs=501, nz=56, uni-directional, "
+                              "mod=None, fwd+bwd+all-reduce+Adam",
+                     metric="DAGs/sec D-VAE train step (ENAS-8node, hs=501, batch 4096)"),
+    "c1": dict(kind="train", mod=None, bidir=False, N=8, C=8, B=32,
+               workload="config 1: ENAS-like 8-node DAGs, batch 32 (the reference's CPU-runnable case)",
+               metric="DAGs/sec D-VAE train step (ENAS-8node, hs=501, batch 32)"),
+    "c2": dict(kind="train", mod="bn", bidir=True, N=10, C=10, B=1024,
+               workload="config 2: Bayesian-network mode (mod='bn', bidirectional, train.py:18-28), 8 variables + SOS/EOS "
+                        "= 10 nodes / 10 types, p=0.3, batch 1024",
+               metric="DAGs/sec D-VAE train step (bn 10-node, hs=501, batch 1024)"),
+    "c3": dict(kind="train", mod=None, bidir=False, N=64, C=8, B=4096,
+               workload="config 3: random 64-node DAGs (p=0.1, orphans -> node 0), uni-directional, batch 4096",
+               metric="DAGs/sec D-VAE train step (64-node random DAGs, hs=501, batch 4096)"),
+    "c4": dict(kind="train", mod=None, bidir=True, N=128, C=8, B=512,
+               workload="config 4: bidirectional encoder, ragged DAGs with 8..128 nodes (p=min(0.5,4/n)), batch 512",
+               metric="DAGs/sec D-VAE train step (ragged 8-128-node DAGs, bidirectional, hs=501, batch 512)"),
+    "c5": dict(kind="decode", mod=None, bidir=False, N=8, C=8, B=100000,
+               workload="config 5: greedy Decoder.predict of 100k latent samples z~N(0,I) to 8-node DAGs",
+               metric="DAGs/sec D-VAE decode (100k latents, 8-node, hs=501)"),
+}
 
-def algorithmic_flops_per_dag(n, e):
-    """SURVEY.md 8(d): forward H^2(34N + 14E) + 12H N(N-1)/2 + 4HZ + 2ZH + 4HCN;
-    train step = 3 x forward (uni-directional, mod None)."""
-    fwd = H * H * (34 * n + 14 * e) + 12 * H * n * (n - 1) / 2 + 4 * H * Z + 2 * Z * H + 4 * H * C * n
+
+def algorithmic_flops(n, e, pairs, mod=None, bidir=False, c=8):
+    """SURVEY.md 8(d), summed over graphs (n = nodes, e = edges, pairs = sum n_b(n_b-1)/2, all per graph
+    on average): forward H^2(34N + 14E) + 12H pairs + 4HZ + 2ZH + 4HCN for mod=None; train step = 3 x
+    forward.  Generalised by the same accounting to the other modes:
+      per node:  encoder sweep + decoder sweep (GRU hidden 6H^2 [+ gate/map 4H^2, mod None only]),
+                 add_vertex 4H^2, W1b 2*H*EH;  per distinct suffix (E+N): W1a 2*H*EH;  per extra suffix
+                 (E-N): GRU 6H^2;  bn: W1c 2*H*EH per graph;  bidirectional: reverse sweep + lin01 4H^2 per node;
+      EH = 4H (None) / 6H (bn)."""
+    eh = 6 * H if mod == "bn" else 4 * H
+    sweep = 6 * H * H if mod == "bn" else 10 * H * H
+    fwd = n * (2 * sweep + 4 * H * H + 2 * H * eh) + (e + n) * 2 * H * eh + (e - n) * 6 * H * H
+    fwd += 3 * eh * pairs + 4 * H * Z + 2 * Z * H + 4 * H * c * n
+    if mod == "bn":
+        fwd += 2 * H * eh
+    if bidir:
+        fwd += n * (sweep + 4 * H * H)
     return 3.0 * fwd
 
 
-def cpu_baseline(threads, seconds_budget=20.0):
-    """The reference's CPU path, restated (oracle/dense_ref.py, checked against the
-    real reference in tests/golden), timed on this box's host cores at the
-    reference's own configuration (config 1: B=32, N=8, C=8)."""
+def decode_flops(n):
+    """SURVEY.md 8(d) decode: H^2(10N + 4N + 8N + 14 N(N-1)/2) per decoded DAG."""
+    return H * H * (22 * n + 14 * n * (n - 1) / 2)
+
+
+def host_cores():
+    """(threads to use, physical cores of the box).  The GPU box gives one job a 16-CPU share of a much
+    larger machine (OMP_NUM_THREADS=16 there); the baseline runs on that share and says so."""
+    phys = set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    nphys = len(phys) or (os.cpu_count() or 1)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or 16
+    return max(1, min(share, avail, nphys)), nphys
+
+
+def cpu_baseline(cfg_name, seconds_budget=20.0):
+    """The reference's CPU path, restated (oracle/dense_ref.py, checked against the real reference in
+    tests/golden), timed on this box's host cores on a bounded sample of the configuration."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dvae_amd
     from oracle import dense_ref as O
+    threads, nphys = host_cores()
     torch.set_num_threads(threads)
-    B = 32
-    model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=None, bidirectional=False))
+    cfg = CONFIGS[cfg_name]
+    S = dvae_amd.synth
+    N, C, mod, bidir = cfg["N"], cfg["C"], cfg["mod"], cfg["bidir"]
+    note = ""
+    if cfg["kind"] == "decode":
+        model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=mod, bidirectional=False, num_classes=C, max_seq=N))
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        M = 256
+        z = torch.randn(M, Z, generator=torch.Generator().manual_seed(0))
+        with torch.no_grad():
+            O.decoder_predict(sd, z[:8], N, C, mod)
+            t0 = time.perf_counter()
+            n = 0
+            while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 50):
+                O.decoder_predict(sd, z, N, C, mod)
+                n += 1
+        dt = (time.perf_counter() - t0) / n
+        return {"value": M / dt, "unit": "DAGs/s", "cores": threads, "host_physical_cores": nphys, "kind": "port",
+                "sample": "%d greedy decodes of %d latents by oracle/dense_ref.py decoder_predict, %.0f ms each"
+                          % (n, M, dt * 1e3)}
+    # dense O(B N^3 H) autograd memory: micro-batches beyond config 1 (SURVEY.md 8d)
+    if cfg_name in ("headline", "c1"):
+        B, N_run, make = 32, N, lambda: S.enas_like(32, 1234)
+        note = "B=32, N=8, C=8 (config 1)"
+    elif cfg_name == "c2":
+        B, N_run, make = 128, N, lambda: S.random_dags(128, N, C, 0.3, 1234, fix_orphans=False)
+        note = "micro-batch B=128, bn, bidirectional, N=C=10"
+    elif cfg_name == "c3":
+        B, N_run, make = 1, 64, lambda: S.random_dags(1, 64, C, 0.1, 1234)
+        note = "micro-batch B=1 at N=64 (the dense path is O(N^3) per graph)"
+    else:   # c4: one mid-size graph of the ragged mix (mean size 68), bidirectional
+        B, N_run, make = 1, 68, lambda: S.random_dags(1, 68, C, 4.0 / 68, 1234)
+        note = "micro-batch B=1 at N=68 (the mean size of the ragged mix), bidirectional"
+    model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=mod, bidirectional=bidir, num_classes=C, max_seq=N_run))
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     opt = torch.optim.Adam(list(sd.values()), lr=1e-4)
-    g, x = dvae_amd.synth.enas_like(B, 1234)
+    g, x = make()
     gen = torch.Generator().manual_seed(0)
 
     def step():
         eps = torch.randn(B, Z, generator=gen)
         opt.zero_grad()
-        loss = O.train_loss(sd, g, x, eps, None, False)[0]
+        loss = O.train_loss(sd, g, x, eps, mod, bidir)[0]
         loss.backward()
         opt.step()
 
-    step()
+    heavy = N_run > 16
+    if not heavy:
+        step()
     t0 = time.perf_counter()
     n = 0
-    while n < 5 or (time.perf_counter() - t0 < seconds_budget and n < 200):
+    while n < (1 if heavy else 5) or (time.perf_counter() - t0 < seconds_budget and n < 200):
         step()
         n += 1
     dt = (time.perf_counter() - t0) / n
-    return {"value": B / dt, "unit": "DAGs/s", "cores": threads, "kind": "port",
-            "sample": "%d train steps (fwd+bwd+Adam) of oracle/dense_ref.py at B=32, N=8, C=8, hs=501 "
-                      "(config 1), %.0f ms/step" % (n, dt * 1e3)}
+    return {"value": B / dt, "unit": "DAGs/s", "cores": threads, "host_physical_cores": nphys, "kind": "port",
+            "sample": "%d train steps (fwd+bwd+Adam) of oracle/dense_ref.py, %s, hs=501, %.0f ms/step"
+                      % (n, note, dt * 1e3)}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """WORLD_SIZE unset and --gpus N > 1: start the N ranks as children of this process, which has not
+    touched the GPU (and never will); their stdout -- rank 0's JSON line -- is ours."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def make_batches(cfg, B_global, rank, world, dev, nb):
+    import dvae_amd
+    from dvae_amd import dp
+    S = dvae_amd.synth
+    N, C = cfg["N"], cfg["C"]
+    batches, stats = [], []
+    for i in range(nb):
+        seed = 100 + i
+        if cfg["N"] == 8:
+            g, x = S.enas_like(B_global, seed)
+            full = {'graph': g, 'node_encoding': x}
+        elif cfg["mod"] == "bn":
+            g, x = S.random_dags(B_global, N, C, 0.3, seed, fix_orphans=False)
+            full = {'graph': g, 'node_encoding': x}
+        elif cfg["bidir"]:
+            g, x, sizes = S.ragged_dags(B_global, C, seed)
+            full = {'graph': g, 'node_encoding': x, 'sizes': sizes}
+        else:
+            g, x = S.random_dags(B_global, N, C, 0.1, seed)
+            full = {'graph': g, 'node_encoding': x}
+        mine = dp.shard_batch(full, rank, world)
+        gb = mine['graph']
+        nodes = mine['sizes'].double() if 'sizes' in mine else torch.full((gb.shape[0],), float(N), dtype=torch.float64)
+        stats.append((gb.shape[0], float(nodes.sum()), float(gb.sum()), float((nodes * (nodes - 1) / 2).sum())))
+        batches.append({k: v.to(dev) for k, v in mine.items()})
+    return batches, stats
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--global-batch", type=int, default=4096)
+    ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
+    ap.add_argument("--global-batch", type=int, default=0, help="override the configuration's batch")
     ap.add_argument("--per-gpu-batch", type=int, default=0, help="weak scaling: fixed batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="build each schedule at the start of its own step")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--stochastic", action="store_true", help="c5: stochastic decode (device uniforms)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: ranks rendezvous over gloo, rank 0 prints the line")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = {"headline": 20, "c1": 50, "c2": 20, "c3": 5, "c4": 8, "c5": 3}[args.config]
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if args.dry_run:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": cfg["metric"], "dry_run": True, "n_gpus": world, "backend": "gloo",
+                              "rccl_ranks": dist.get_world_size(), "allreduce_sum": float(t)}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -97,59 +277,64 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import dvae_amd
-    from dvae_amd import _lib
+    from dvae_amd import _lib, dp
 
     weak = args.per_gpu_batch > 0
-    B_local = args.per_gpu_batch if weak else args.global_batch // world
-    B_global = B_local * world
+    B_cfg = args.global_batch or cfg["B"]
+    B_global = args.per_gpu_batch * world if weak else B_cfg
+    lo, hi = dp.shard_range(B_global, rank, world)
+    B_local = hi - lo
+    N, C = cfg["N"], cfg["C"]
 
     torch.manual_seed(0)
-    model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=None, bidirectional=False)).to(dev)
+    model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=cfg["mod"], bidirectional=cfg["bidir"],
+                                    num_classes=C, max_seq=N)).to(dev)
     if dist is not None:
         for p in model.parameters():
             dist.broadcast(p.data, 0)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-
-    from dvae_amd import dp
-    # a few distinct batches per rank, generated once, resident in HBM
-    nb = 4
-    batches, e_sum = [], 0.0
-    for i in range(nb):
-        g, x = dvae_amd.synth.enas_like(B_global, 100 + i)
-        lo, hi = dp.shard_range(B_global, rank, world)
-        sl = slice(lo, hi)
-        e_sum += float(g[sl].sum()) / B_local
-        batches.append({'graph': g[sl].to(dev), 'node_encoding': x[sl].to(dev)})
-    mean_e = e_sum / nb
-
-    sync_grads = dp.make_grad_sync(dist, force=force_dist)       # SUM all-reduce: the losses are sums (dvae_model.py:405)
-
-    # the level schedule of batch i+1 is queued (own stream) as soon as step i has been
-    # launched, as a prefetching data loader would: every step still builds one schedule
-    # inside the timed region, but nobody waits for its host round trip
-    # (multi-GPU runs queue it on the library's side stream at the start of the step: with RCCL's
-    # streams a prefetch stream would be the fifth stream of the process and the box gives a process
-    # 4 hardware queues)
-    prepared = {}
-    prefetch = not args.no_prefetch
-    on_side = dist is not None     # with RCCL in the process: no third stream, the side stream builds it
-
-    def step(i):
-        sched = prepared.pop(i, None)
-        if prefetch and on_side:   # queued ahead of this step's own side-stream work (idle until the decoder starts)
-            prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True, on_side_stream=True)
-        out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads, sched=sched)
-        if prefetch and not on_side:
-            prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True)
-        opt.step()
-        return out4
+    lib = _lib.load()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    lib = _lib.load()
+    if cfg["kind"] == "decode":
+        # embarrassingly parallel: every rank decodes its contiguous shard of the latents, no collective
+        z = torch.randn(B_global, Z, generator=torch.Generator().manual_seed(0))[lo:hi].to(dev)
+        mean_n, mean_e, mean_pairs = float(N), 0.0, N * (N - 1) / 2
+        out = None
+
+        def step(i):
+            return model.decoder.predict(z, is_stochastic=args.stochastic)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+        nb = 4 if cfg["N"] <= 16 else 2      # a few distinct batches per rank, generated once, resident in HBM
+        batches, stats = make_batches(cfg, B_global, rank, world, dev, nb)
+        cnt = sum(s[0] for s in stats)
+        mean_n, mean_e, mean_pairs = (sum(s[k] for s in stats) / cnt for k in (1, 2, 3))
+        sync_grads = dp.make_grad_sync(dist, force=force_dist)   # SUM all-reduce: the losses are sums (dvae_model.py:405)
+
+        # the level schedule of batch i+1 is queued (own stream) as soon as step i has been
+        # launched, as a prefetching data loader would: every step still builds one schedule
+        # inside the timed region, but nobody waits for its host round trip
+        # (multi-GPU runs queue it on the library's side stream at the start of the step: with RCCL's
+        # streams a prefetch stream would be the fifth stream of the process and the box gives a process
+        # 4 hardware queues)
+        prepared = {}
+        prefetch = not args.no_prefetch
+        on_side = dist is not None     # with RCCL in the process: no third stream, the side stream builds it
+
+        def step(i):
+            sched = prepared.pop(i, None)
+            if prefetch and on_side:   # queued ahead of this step's own side-stream work (idle until the decoder starts)
+                prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True, on_side_stream=True)
+            out4 = model.loss_and_grad(batches[i % nb], grad_sync=sync_grads, sched=sched)
+            if prefetch and not on_side:
+                prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True)
+            opt.step()
+            return out4
+
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -163,7 +348,7 @@ def main():
         if sample:
             lib.dvae_gemm_profile(2 if prof_steps else 1)
             prof_steps += 1
-        out4 = step(args.warmup + i)
+        out = step(args.warmup + i)
         if sample:
             lib.dvae_gemm_profile(0)
     barrier()
@@ -173,32 +358,48 @@ def main():
         buf = (ctypes.c_double * 12)()
         _lib.check(lib.dvae_gemm_profile_read(ctypes.cast(buf, ctypes.c_void_p)))
         gemm = list(buf)
+    rccl_ranks = None
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(out4[3])
-    assert math.isfinite(loss), "loss is not finite"
+        rccl_ranks = dist.get_world_size()
+    if cfg["kind"] == "train":
+        final = float(out[3])
+        assert math.isfinite(final), "loss is not finite"
+    else:
+        final = float(out[0].sum()) / B_local        # mean edges per decoded DAG
+        mean_e = final
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = B_global * args.steps / dt
         res = {
-            "metric": "DAGs/sec D-VAE train step (ENAS-8node, hs=501, batch 4096)",
+            "metric": cfg["metric"] if B_global == cfg["B"] else cfg["metric"] + " [batch %d]" % B_global,
             "value": value, "unit": "DAGs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ENAS-like 8-node DAGs (chain + p=1/3), nvt=8, hs=501, nz=56, "
-                                   "uni-directional, mod=None, fwd+bwd+all-reduce+Adam",
-                       "global_batch": B_global, "per_gpu_batch": B_local, "mean_edges": round(mean_e, 2),
-                       "depth": 7, "parallelism": "dp%d" % world, "final_loss": loss},
+            "config": {"workload": cfg["workload"], "name": args.config,
+                       "global_batch": B_global, "per_gpu_batch": B_local, "mean_nodes": round(mean_n, 2),
+                       "mean_edges": round(mean_e, 2), "parallelism": "dp%d" % world},
         }
+        if cfg["kind"] == "train":
+            res["config"]["final_loss"] = final
+            if cfg["N"] <= 16:
+                g0 = batches[0]['graph'][:256].cpu()
+                res["config"]["depth"] = round(dvae_amd.synth.graph_stats(g0)[1], 2)
+        if rccl_ranks is not None:
+            res["rccl_ranks"] = rccl_ranks
         if gemm is not None:
             # dominant kernel: gemm_f32_kernel (all three layouts are one template)
             launches = gemm[0] + gemm[3] + gemm[9]
             kms = gemm[1] + gemm[4] + gemm[10]
             executed = gemm[2] + gemm[5] + gemm[11]
-            algo = algorithmic_flops_per_dag(N, mean_e) * B_local * prof_steps
+            if cfg["kind"] == "train":
+                per_dag = algorithmic_flops(mean_n, mean_e, mean_pairs, cfg["mod"], cfg["bidir"], C)
+            else:
+                per_dag = decode_flops(N)
+            algo = per_dag * B_local * prof_steps
             busy = gemm[6] if gemm[6] > 0 else kms     # wall time with >= 1 GEMM launch running
             ach = algo / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
             res["roofline"] = {
@@ -209,13 +410,15 @@ def main():
                 "sum_launch_ms_per_step": kms / prof_steps, "timed_steps_with_events": prof_steps,
                 "avg_launch_us": kms / max(launches, 1) * 1e3,
                 "executed_tflops": executed / (busy * 1e-3) / 1e12 if busy > 0 else 0.0,
+                "whole_step_tflops": per_dag * B_local / (ms * 1e-3) / 1e12,
                 "note": "HIP events around every launch of the kernel on every %d-th timed step; launches run on "
                         "two streams and overlap: achieved = algorithmic FLOPs / wall time with at least one "
-                        "launch of the kernel running; avg_launch_us is the plain per-launch mean" % PROF_EVERY,
-                "algorithmic_gflop_per_dag": algorithmic_flops_per_dag(N, mean_e) / 1e9,
+                        "launch of the kernel running; avg_launch_us is the plain per-launch mean; "
+                        "executed_tflops counts the FLOPs the launches really did" % PROF_EVERY,
+                "algorithmic_gflop_per_dag": per_dag / 1e9,
             }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+            res["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
