@@ -20,6 +20,7 @@ extern "C" int dvae_dims_init(dvae_dims* d) {
   DVAE_REQUIRE(d, "dims: null");
   DVAE_REQUIRE(d->B > 0, "dims: B must be positive");
   DVAE_REQUIRE(d->N > 0 && d->N <= DVAE_MAX_N, "dims: N must be in [1,%d]", DVAE_MAX_N);
+  DVAE_REQUIRE(sched_sizes_ok(d->B, d->N), "dims: batch too large for int32 row indices (B*N < 2^30 and B*N*(N+1)/2 < 2^31; got B=%d N=%d)", d->B, d->N);
   DVAE_REQUIRE(d->C > 0 && d->C < DVAE_MAX_C, "dims: C must be in [1,%d]", DVAE_MAX_C);
   DVAE_REQUIRE(d->H > 0 && d->H <= 2048 && d->Z > 0 && d->Z <= 1024, "dims: H/Z out of range");
   DVAE_REQUIRE(d->mod == 0 || d->mod == 1, "dims: mod must be 0 (None) or 1 ('bn')");

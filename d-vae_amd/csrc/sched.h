@@ -50,6 +50,7 @@ __host__ __device__ static inline int final_prow(const SchedDir& S, int R, int r
   return e1 == S.csr_ptr[r] ? r : R + e1 - 1;
 }
 SchedView sched_view(void* base, int B, int N);
+bool sched_sizes_ok(int B, int N);   // every int32 row / edge index of a [B][N][N] batch fits
 
 // Decoder k = 0 prefix rows of levels >= 1 have h_in = 0, so their GRU state -- and with it
 // their add_edge first-layer row A = W1a.hv -- depends on the node TYPE only.  When every

@@ -405,7 +405,16 @@ extern "C" int dvae_sched_types(const float* x, int B, int N, int C, void* sched
   return DVAE_OK;
 }
 
+// every row / edge index of a schedule is an int32: node rows B*N, candidate pairs B*N*(N-1)/2 and the
+// decoder's prefix rows (their sum) must all stay below 2^31
+bool sched_sizes_ok(int B, int N) {
+  if (B <= 0 || N <= 0 || N > DVAE_MAX_N) return false;
+  const long long rows = (long long)B * N, pairs = rows * (N - 1) / 2;
+  return rows < (1ll << 30) && rows + pairs < (1ll << 31) - 64;
+}
+
 extern "C" size_t dvae_sched_bytes(int B, int N) {
+  if (!sched_sizes_ok(B, N)) return 0;   // dvae_sched_build reports the reason
   size_t total = 0;
   carve(nullptr, B, N, &total);
   return total;
@@ -415,7 +424,7 @@ extern "C" int dvae_sched_build(const float* g, const int* sizes, int B, int N, 
                                 void* sched, int* info_host, void* stream) {
   DVAE_REQUIRE(B > 0 && N > 0 && N <= DVAE_MAX_N, "sched: need B>0 and 0<N<=%d (got B=%d N=%d)",
                DVAE_MAX_N, B, N);
-  DVAE_REQUIRE((long long)B * N < (1ll << 30), "sched: B*N too large");
+  DVAE_REQUIRE(sched_sizes_ok(B, N), "sched: batch too large for int32 row indices (B*N < 2^30 and B*N*(N+1)/2 < 2^31; got B=%d N=%d)", B, N);
   DVAE_REQUIRE(g && sched && info_host, "sched: null pointer");
   hipStream_t st = (hipStream_t)stream;
   SchedView s = sched_view(sched, B, N);

@@ -86,14 +86,18 @@ class Schedule:
         _require_cuda(g, "X['graph']")
         assert g.dim() == 3 and g.shape[1] == g.shape[2], "graph must be [B,N,N]"
         lib = load()
-        self.g = _f32c(g)
         self.B, self.N = int(g.shape[0]), int(g.shape[1])
-        self.sizes = None if sizes is None else sizes.detach().to(device=g.device, dtype=torch.int32).contiguous()
         self.want_reverse = bool(want_reverse)
         self.stream = stream if stream is not None else torch.cuda.current_stream()
+        self._x = None
         with torch.cuda.stream(self.stream):
+            # dtype / layout conversions run on the build stream too: queued on the caller's stream they
+            # would not be ordered before the build kernels (Dvae.prepare builds on a stream of its own),
+            # and their results would belong to another stream's allocator pool
+            self.g = _f32c(g)
+            self.sizes = None if sizes is None else sizes.detach().to(device=g.device, dtype=torch.int32).contiguous()
             nbytes = lib.dvae_sched_bytes(self.B, self.N)
-            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)
             self._pin = _pinned_info(g.device.index, _lib.sched_info_ints(self.N))
             check(lib.dvae_sched_build(_ptr(self.g), _ptr(self.sizes), self.B, self.N, int(self.want_reverse),
                                        _ptr(self.buf), ctypes.c_void_p(self._pin.data_ptr()),
@@ -127,7 +131,9 @@ class Schedule:
         """Order `stream` after the build (no-op on the build's own stream)."""
         if stream != self.stream:
             stream.wait_event(self.event)
-            self.buf.record_stream(stream)
+            for t in (self.buf, self.g, self.sizes, self._x):   # built (and perhaps converted) on the build stream
+                if t is not None:
+                    t.record_stream(stream)
 
     @property
     def info(self):
@@ -365,17 +371,21 @@ class EncoderFn(torch.autograd.Function):
         dims = _dims_for(module._dims, sched.B, sched.N)
         P = module._pack.pack(dims, params)
         call = EncoderCall(dims, sched, x, P)
-        ctx.call, ctx.module, ctx.params = call, module, params
+        ctx.call, ctx.module = call, module
+        # the backward reads the module's shared packed copy P: saving the parameters lets autograd's version
+        # check refuse a backward after an in-place weight change (optimizer.step between forward and backward)
+        ctx.save_for_backward(*params)
         return call.hv, call.mu, call.logvar
 
     @staticmethod
     def backward(ctx, d_hv, d_mu, d_logvar):
         pack = ctx.module._pack
+        params = ctx.saved_tensors
         G = pack.new_packed_grad()
         cont = lambda t: None if t is None else t.contiguous()
         flat = _bwd_on_two_streams(
             pack, G, lambda side: ctx.call.backward(cont(d_hv), cont(d_mu), cont(d_logvar), G, side=side))[0]
-        grads = pack.views(flat, ctx.params)
+        grads = pack.views(flat, params)
         ctx.call = None
         return (None, None, None) + tuple(grads)
 
@@ -389,17 +399,19 @@ class DecoderFn(torch.autograd.Function):
         side = side_stream(x.device)       # add_edge's first layer and add_vertex run beside the level chain;
         side.wait_stream(main)             # the library orders the side stream back into `main` before it returns
         call = DecoderCall(dims, sched, _f32c(z), x, P, side=side)
-        ctx.call, ctx.module, ctx.params = call, module, params
+        ctx.call, ctx.module = call, module
+        ctx.save_for_backward(*params)      # version check, as in EncoderFn
         ctx.need_dz = z.requires_grad
         return call.edge_logits, call.type_logits
 
     @staticmethod
     def backward(ctx, d_edge, d_type):
         pack = ctx.module._pack
+        params = ctx.saved_tensors
         G = pack.new_packed_grad()
         flat, d_z = _bwd_on_two_streams(
             pack, G, lambda side: ctx.call.backward(d_edge.contiguous(), d_type.contiguous(), G, want_dz=True, side=side))
-        grads = pack.views(flat, ctx.params)
+        grads = pack.views(flat, params)
         ctx.call = None
         return (None, None, d_z, None) + tuple(grads)
 

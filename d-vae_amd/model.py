@@ -351,7 +351,6 @@ class Dvae(nn.Module):
         still running -- and may return a handle with ``.wait()``.  ``sched``: the
         result of ``prepare(batch)`` for this batch (built ahead of time).
         Returns the device tensor [edge_loss, vertex_loss, kl_loss, loss]."""
-        assert not self._shared_gm, "loss_and_grad does not support same_mapper_gater; use training_step"
         g, x, sizes = _batch_parts(batch)
         self.encoder._check(g, x)
         enc, dec = self.encoder, self.decoder
@@ -402,11 +401,18 @@ class Dvae(nn.Module):
                 if grad_sync is not None:
                     handles.append(grad_sync(fe))
             main.wait_stream(side)
-            for p, v in zip(enc_p, enc._pack.views(fe, enc_p)):
-                p.grad = v
-            for p, v in zip(dec_p, dec._pack.views(fd, dec_p)):
-                p.grad = v
             for h in handles:
                 if h is not None:
                     h.wait()
+            ev = enc._pack.views(fe, enc_p)
+            for p, v in zip(enc_p, ev):
+                p.grad = v
+            owner = {id(p): v for p, v in zip(enc_p, ev)} if self._shared_gm else {}
+            for p, v in zip(dec_p, dec._pack.views(fd, dec_p)):
+                if id(p) in owner:
+                    # same_mapper_gater (:382-399): one gate/map network serves both modules; its gradient is
+                    # the sum of the two modules' parts (each already all-reduced with its buffer)
+                    owner[id(p)].add_(v)
+                else:
+                    p.grad = v
         return out4

@@ -106,7 +106,8 @@ class _EncFn(torch.autograd.Function):
         d = _dims(module._dims, B, T)
         P = module._pack.pack(d, params)
         ws, mu, logvar = _enc_fwd(d, x, P)
-        ctx.d, ctx.P, ctx.ws, ctx.module, ctx.params = d, P, ws, module, params
+        ctx.d, ctx.P, ctx.ws, ctx.module = d, P, ws, module
+        ctx.save_for_backward(*params)     # autograd's version check guards the shared packed copy P (engine.EncoderFn)
         return mu, logvar
 
     @staticmethod
@@ -116,7 +117,7 @@ class _EncFn(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         d_mu, d_logvar = cont(d_mu), cont(d_logvar)
         flat = _two_streams(pack, G, lambda side: _enc_bwd(ctx.d, ctx.P, ctx.ws, d_mu, d_logvar, G, side))[0]
-        grads = pack.views(flat, ctx.params)
+        grads = pack.views(flat, ctx.saved_tensors)
         ctx.ws = None
         return (None, None) + tuple(grads)
 
@@ -127,7 +128,8 @@ class _DecFn(torch.autograd.Function):
         d = _dims(module._dims, z.shape[0], module.max_seq_len - 1)
         P = module._pack.pack(d, params)
         ws, ts, es = _dec_fwd(d, _f32c(z), P)
-        ctx.d, ctx.P, ctx.ws, ctx.module, ctx.params = d, P, ws, module, params
+        ctx.d, ctx.P, ctx.ws, ctx.module = d, P, ws, module
+        ctx.save_for_backward(*params)     # autograd's version check guards the shared packed copy P (engine.EncoderFn)
         return ts, es
 
     @staticmethod
@@ -137,7 +139,7 @@ class _DecFn(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         d_ts, d_es = cont(d_ts), cont(d_es)
         flat, d_z = _two_streams(pack, G, lambda side: _dec_bwd(ctx.d, ctx.P, ctx.ws, d_ts, d_es, G, side))
-        grads = pack.views(flat, ctx.params)
+        grads = pack.views(flat, ctx.saved_tensors)
         ctx.ws = None
         return (None, d_z) + tuple(grads)
 

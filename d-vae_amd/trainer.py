@@ -86,13 +86,27 @@ class Trainer:
         dev = self._device(model)
         rank, world = self._world()
         sync = dp.make_grad_sync(self.dist)
-        fused = self.fused and hasattr(model, 'loss_and_grad') and not getattr(model, '_shared_gm', False)
+        fused = self.fused and hasattr(model, 'loss_and_grad')
+        if world > 1:
+            # data parallel = the single-device big-batch step (dp.py) only if every rank starts from the
+            # same weights and walks the same shuffled batches: rank 0's parameters and a per-epoch
+            # shuffle seed are broadcast
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    self.dist.broadcast(t.data, 0)
         while self.epoch < self.max_epochs:
             model.train()
             sums, steps = torch.zeros(4, dtype=torch.float64), 0
+            if world > 1:
+                seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(dev)
+                self.dist.broadcast(seed, 0)
+                torch.manual_seed(int(seed.item()))     # the loader's RandomSampler seeds itself from this generator
             for i, batch in enumerate(model.train_dataloader()):
                 if self.max_steps is not None and i >= self.max_steps:
                     break
+                if world > 1 and next(v for v in batch.values() if torch.is_tensor(v)).shape[0] < world:
+                    continue    # a tail batch with fewer graphs than ranks would leave a rank without work (the
+                                # reference's loader has no drop_last, dataloader.py:118-126): all ranks drop it
                 batch = _to_device(dp.shard_batch(batch, rank, world) if world > 1 else batch, dev)
                 if fused:
                     out4 = model.loss_and_grad(batch, grad_sync=sync)

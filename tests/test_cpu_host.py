@@ -44,6 +44,23 @@ def test_dims_and_errors():
         _lib.make_dims(4, 8, 8, 501, 56, 'nn', False, 8)
 
 
+def test_batches_beyond_int32_row_indices_are_rejected():
+    """B*N*(N-1)/2 candidate pairs (and the decoder's prefix rows) are int32 indices: a batch that
+    overflows them is refused by every size query instead of being clamped (no GPU needed)."""
+    from dvae_amd import _lib
+    lib = _lib.load()
+    assert lib.dvae_sched_bytes(4096, 128) > 0
+    assert lib.dvae_sched_bytes(270000, 128) == 0            # 270000*128*127/2 > 2^31
+    assert lib.dvae_sched_bytes(1 << 24, 64) == 0            # B*N >= 2^30
+    assert lib.dvae_sched_bytes(0, 8) == 0 and lib.dvae_sched_bytes(8, 129) == 0
+    with pytest.raises(_lib.DvaeError, match="int32 row indices"):
+        _lib.make_dims(270000, 128, 8, 501, 56, None, False, 128)
+    dummy = ctypes.c_void_p(256)                             # never dereferenced: the size check comes first
+    rc = lib.dvae_sched_build(dummy, None, 270000, 128, 0, dummy, dummy, None)
+    assert rc == -1 and b"int32 row indices" in lib.dvae_last_error()
+    _lib.make_dims(100000, 8, 8, 501, 56, None, False, 8)   # config 5's decode batch is fine
+
+
 @pytest.mark.parametrize("mod,bidir,N,C,count", [(None, False, 8, 8, 5165932), (None, True, 8, 8, 6947488),
                                                   ("bn", False, 10, 10, 6685968), ("bn", True, 10, 10, 7970532)])
 def test_state_dict_surface(mod, bidir, N, C, count):
