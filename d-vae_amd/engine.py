@@ -4,6 +4,7 @@ the ELBO.  torch is plumbing here (device memory, streams, autograd graph); all
 arithmetic of the hot path happens in libdvae_hip.so.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -53,6 +54,26 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+_POISON = bool(os.environ.get("DVAE_POISON_WS"))
+
+
+def _workspace(nbytes, device):
+    """Uninitialised device bytes for a *_ws_bytes workspace.  DVAE_POISON_WS=1 (test aid) fills it with
+    0xFF bytes -- NaN as floats, -1 as ints -- so that a kernel reading a location nothing wrote shows
+    up as NaN results instead of depending on what the allocator handed back."""
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if _POISON:
+        ws.fill_(255)
+    return ws
+
+
+def _out(*shape, device):
+    t = torch.empty(*shape, device=device)
+    if _POISON:
+        t.fill_(float('nan'))
+    return t
+
+
 # ---------------------------------------------------------------------------
 # level schedule of one batch
 # ---------------------------------------------------------------------------
@@ -97,7 +118,7 @@ class Schedule:
             self.g = _f32c(g)
             self.sizes = None if sizes is None else sizes.detach().to(device=g.device, dtype=torch.int32).contiguous()
             nbytes = lib.dvae_sched_bytes(self.B, self.N)
-            self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)
+            self.buf = _workspace(max(int(nbytes), 256), g.device)
             self._pin = _pinned_info(g.device.index, _lib.sched_info_ints(self.N))
             check(lib.dvae_sched_build(_ptr(self.g), _ptr(self.sizes), self.B, self.N, int(self.want_reverse),
                                        _ptr(self.buf), ctypes.c_void_p(self._pin.data_ptr()),
@@ -241,7 +262,7 @@ class ParamPack:
     def unpack(self, G, flat=None):
         """packed gradient buffer -> flat reference-shaped gradients (views returned)."""
         if flat is None:
-            flat = torch.empty(self.total, dtype=torch.float32, device=G.device)
+            flat = _out(self.total, device=G.device)
         check(load().dvae_unpack_grads(_ptr(self.table), self.n, _ptr(G), _ptr(flat), _stream()))
         return flat
 
@@ -267,10 +288,10 @@ class EncoderCall:
         self.dims, self.sched, self.x, self.P = dims, sched, x, P
         dev = x.device
         B = dims.B
-        self.ws = torch.empty(lib.dvae_enc_ws_bytes(ctypes.byref(dims), sched.R, sched.E), dtype=torch.uint8, device=dev)
-        self.hv = torch.empty(B, dims.H, device=dev)
-        self.mu = torch.empty(B, dims.Z, device=dev)
-        self.logvar = torch.empty(B, dims.Z, device=dev)
+        self.ws = _workspace(lib.dvae_enc_ws_bytes(ctypes.byref(dims), sched.R, sched.E), dev)
+        self.hv = _out(B, dims.H, device=dev)
+        self.mu = _out(B, dims.Z, device=dev)
+        self.logvar = _out(B, dims.Z, device=dev)
         self.states = torch.empty(B, dims.N, dims.H, device=dev) if want_states else None
         self.states_rev = torch.empty(B, dims.N, dims.H, device=dev) if (want_states and dims.bidir) else None
         check(lib.dvae_encoder_fwd(ctypes.byref(dims), _ptr(x), _ptr(sched.sizes), _ptr(sched.buf), sched.info_ptr,
@@ -290,9 +311,9 @@ class DecoderCall:
         self.dims, self.sched, self.z, self.x, self.P = dims, sched, z, x, P
         dev = x.device
         B, N = dims.B, dims.N
-        self.ws = torch.empty(lib.dvae_dec_ws_bytes(ctypes.byref(dims), sched.R, sched.E), dtype=torch.uint8, device=dev)
-        self.edge_logits = torch.empty(B, N, N, device=dev)
-        self.type_logits = torch.empty(B, N, dims.C, device=dev)
+        self.ws = _workspace(lib.dvae_dec_ws_bytes(ctypes.byref(dims), sched.R, sched.E), dev)
+        self.edge_logits = _out(B, N, N, device=dev)
+        self.type_logits = _out(B, N, dims.C, device=dev)
         self.states = torch.empty(B, N, dims.H, device=dev) if want_states else None
         check(lib.dvae_decoder_fwd(ctypes.byref(dims), _ptr(z), _ptr(x), _ptr(sched.sizes), _ptr(sched.buf),
                                    sched.info_ptr, _ptr(P), _ptr(self.ws), _ptr(self.edge_logits),
@@ -300,7 +321,7 @@ class DecoderCall:
 
     def backward(self, d_edge, d_type, G, want_dz=True, side=None):
         s = self.sched
-        d_z = torch.empty_like(self.z) if want_dz else None
+        d_z = _out(*self.z.shape, device=self.z.device) if want_dz else None
         check(load().dvae_decoder_bwd(ctypes.byref(self.dims), _ptr(self.z), _ptr(self.x), _ptr(s.sizes), _ptr(s.buf),
                                       s.info_ptr, _ptr(self.P), _ptr(self.ws), _ptr(d_edge), _ptr(d_type), _ptr(G),
                                       _ptr(d_z), _stream(), _side(side)))
@@ -310,12 +331,11 @@ class DecoderCall:
 def elbo_call(dims, edge_logits, type_logits, g, x, sizes, mu, logvar, beta, want_grads):
     lib = load()
     dev = g.device
-    out4 = torch.empty(4, device=dev)
-    part = torch.empty(lib.dvae_elbo_ws_bytes(dims.B), dtype=torch.uint8, device=dev)
+    out4 = _out(4, device=dev)
+    part = _workspace(lib.dvae_elbo_ws_bytes(dims.B), dev)
     grads = (None, None, None, None)
     if want_grads:
-        grads = (torch.empty_like(edge_logits), torch.empty_like(type_logits), torch.empty_like(mu),
-                 torch.empty_like(logvar))
+        grads = tuple(_out(*t.shape, device=dev) for t in (edge_logits, type_logits, mu, logvar))
     check(lib.dvae_elbo(ctypes.byref(dims), _ptr(edge_logits), _ptr(type_logits), _ptr(g), _ptr(x), _ptr(sizes),
                         _ptr(mu), _ptr(logvar), ctypes.c_float(beta), _ptr(out4), _ptr(part), _ptr(grads[0]),
                         _ptr(grads[1]), _ptr(grads[2]), _ptr(grads[3]), _stream()))
@@ -338,9 +358,9 @@ def predict_call(dims, z, P, u_type=None, u_edge=None, want_margin=False):
     lib = load()
     dev = z.device
     M, N, C = dims.B, dims.N, dims.C
-    ws = torch.empty(lib.dvae_predict_ws_bytes(ctypes.byref(dims)), dtype=torch.uint8, device=dev)
-    edges = torch.empty(M, N, N, device=dev)
-    onehot = torch.empty(M, N, C, device=dev)
+    ws = _workspace(lib.dvae_predict_ws_bytes(ctypes.byref(dims)), dev)
+    edges = _out(M, N, N, device=dev)
+    onehot = _out(M, N, C, device=dev)
     margin = torch.empty(1, device=dev) if want_margin else None
     check(lib.dvae_decoder_predict(ctypes.byref(dims), _ptr(z), _ptr(P), _ptr(ws), _ptr(u_type), _ptr(u_edge),
                                    _ptr(edges), _ptr(onehot), _ptr(margin), _stream()))
@@ -357,7 +377,7 @@ def _bwd_on_two_streams(pack, G, run):
     main = torch.cuda.current_stream()
     side = side_stream(G.device)
     side.wait_stream(main)
-    flat = torch.empty(pack.total, dtype=torch.float32, device=G.device)   # owned by `main`'s allocator pool
+    flat = _out(pack.total, device=G.device)   # owned by `main`'s allocator pool
     res = run(side)
     with torch.cuda.stream(side):
         pack.unpack(G, flat)

@@ -48,6 +48,14 @@ def _worker(rank, world, port, ret):
         ret['grad_max'] = float((grads - ref).abs().max() / ref.abs().max())
         ret['loss_err'] = float((losses - ref4).abs().max() / ref4.abs().max())
         ret['rows'] = int(mine['graph'].shape[0])
+        # where a mismatch sits (reported with a failure): worst parameters by relative error
+        per, off = [], 0
+        for k, p in model.named_parameters():
+            n = p.numel()
+            d = float((grads[off:off + n] - ref[off:off + n]).norm() / (ref[off:off + n].norm() + 1e-30))
+            per.append((round(d, 6), k))
+            off += n
+        ret['worst'] = sorted(per, reverse=True)[:6]
     dist.barrier()
     dist.destroy_process_group()
 
