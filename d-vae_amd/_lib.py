@@ -92,6 +92,7 @@ SIGNATURES = {
     "dvae_reparam_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     "dvae_elbo_ws_bytes": (c_size_t, [c_int]),
     "dvae_elbo": (c_int, [_P(DvaeDims)] + [c_void_p] * 7 + [c_float] + [c_void_p] * 7),
+    "dvae_elbo_static": (c_int, [_P(DvaeDims)] + [c_void_p] * 7 + [c_float] + [c_void_p] * 6),
     "dvae_predict_ws_bytes": (c_size_t, [_P(DvaeDims)]),
     "dvae_decoder_predict": (c_int, [_P(DvaeDims)] + [c_void_p] * 9),
     "dvae_svae_dims_init": (c_int, [_P(SvaeDims)]),

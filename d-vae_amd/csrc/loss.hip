@@ -2,7 +2,37 @@
 // Reference: dvae_model.py:410-413 (reparamterize), :425-432 / :447-454 (losses).
 #include "common.h"
 
+#include <mutex>
+
 namespace {
+
+// ---- dvae_elbo_static: the per-graph partial sums of the ELBO in library-owned device memory ----
+// One copy of this array lives on every GPU the library runs on, for the life of the process
+// (DVAE_ELBO_STATIC_MAX_B * 3 doubles = 1.5 MiB).  In host code the NAME below is only a handle for
+// hipGetSymbolAddress: the device address is looked up once per device (elbo_scratch_ptr) and only that
+// pointer is ever given to a kernel.
+constexpr int ELBO_STATIC_MAX_B = 65536;
+static __device__ __align__(256) double scratch[(size_t)ELBO_STATIC_MAX_B * 3];
+
+constexpr int MAX_DEVICES = 64;
+double* g_scratch_ptr[MAX_DEVICES] = {};
+std::mutex g_scratch_mu;
+
+// device address of `scratch` on the CURRENT device (resolved on the first call per device)
+int elbo_scratch_ptr(double** out) {
+  int dev = -1;
+  DVAE_CHECK_HIP(hipGetDevice(&dev));
+  DVAE_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "elbo_static: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    DVAE_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    DVAE_REQUIRE(p != nullptr, "elbo_static: hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[dev] = static_cast<double*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return DVAE_OK;
+}
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -129,6 +159,24 @@ extern "C" int dvae_reparam_bwd(const float* d_z, const float* logvar, const flo
 }
 
 extern "C" size_t dvae_elbo_ws_bytes(int B) { return (size_t)B * 3 * sizeof(double) + 256; }
+
+// dvae_elbo without a caller workspace and without any allocation: the partial sums go to the library's
+// own per-device array (see `scratch` above).  Same kernels, same results, bit for bit.
+extern "C" int dvae_elbo_static(const dvae_dims* d, const float* edge_logits, const float* type_logits,
+                                const float* g, const float* x, const int* sizes, const float* mu,
+                                const float* logvar, float beta, float* out4, float* d_edge, float* d_type,
+                                float* d_mu, float* d_logvar, void* stream) {
+  DVAE_REQUIRE(d, "elbo_static: null pointer");
+  DVAE_REQUIRE(d->B >= 1 && d->B <= ELBO_STATIC_MAX_B,
+               "elbo_static: B=%d graphs, the static workspace holds at most %d (use dvae_elbo with a caller workspace)",
+               d->B, ELBO_STATIC_MAX_B);
+  double* part = nullptr;
+  DVAE_TRY(elbo_scratch_ptr(&part));
+  // elbo_kernel writes partial[0 .. 3B) before elbo_final_kernel reads exactly that range: nothing left by an
+  // earlier (larger) call is ever read, so no clearing is needed
+  return dvae_elbo(d, edge_logits, type_logits, g, x, sizes, mu, logvar, beta, out4, part, d_edge, d_type, d_mu,
+                   d_logvar, stream);
+}
 
 extern "C" int dvae_elbo(const dvae_dims* d, const float* edge_logits, const float* type_logits, const float* g,
                          const float* x, const int* sizes, const float* mu, const float* logvar, float beta,

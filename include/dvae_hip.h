@@ -262,6 +262,20 @@ int dvae_elbo(const dvae_dims* d, const float* edge_logits, const float* type_lo
               const float* logvar, float beta, float* out4, void* partial, float* d_edge,
               float* d_type, float* d_mu, float* d_logvar, void* stream);
 
+/* dvae_elbo for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving / evaluation loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.
+ * Same arguments as dvae_elbo minus `partial`: the per-graph partial sums live in a file-scope
+ * device array inside the library (1.5 MiB per GPU, held until the process ends), whose address is
+ * resolved with hipGetSymbolAddress on the first call on each device.  The call itself performs no
+ * hipMalloc / hipFree.  Limit: d->B <= 65536 graphs (DVAE_ERR_ARG beyond that).  All calls on one
+ * GPU share the array: calls that overlap on one GPU (two streams, two threads) race; calls ordered
+ * on one stream are safe.  Results are bit-identical to dvae_elbo's. */
+#define DVAE_ELBO_STATIC_MAX_B 65536
+int dvae_elbo_static(const dvae_dims* d, const float* edge_logits, const float* type_logits,
+                     const float* g, const float* x, const int* sizes, const float* mu,
+                     const float* logvar, float beta, float* out4, float* d_edge, float* d_type,
+                     float* d_mu, float* d_logvar, void* stream);
+
 /* ------------------------------------------------------------------------
  * Autoregressive decode (dvae_model.py:263-362).  u_type [M][N] / u_edge
  * [M][N][N] are injected uniforms for the stochastic mode, NULL for greedy.
