@@ -874,8 +874,12 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
 
   // ---- lin1 ----
-  DVAE_TRY(g.tn(w.DH0, HP, w.ZPAD, d.ZP, Gp + L.Wl1, d.ZP, HP, d.ZP, B));
-  DVAE_TRY(k_colsum(w.DH0, HP, B, HP, Gp + L.bl1, msc.part, msc.part_floats, st));
+  // its weight gradients go to the side stream like every other write to G: the caller orders its use of G
+  // after the SIDE stream only (include/dvae_hip.h), so a write to G queued on the chain would race with the
+  // caller's unpack whenever the side stream drains first (small batches)
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(gs.tn(w.DH0, HP, w.ZPAD, d.ZP, Gp + L.Wl1, d.ZP, HP, d.ZP, B));
+  DVAE_TRY(k_colsum(w.DH0, HP, B, HP, Gp + L.bl1, ssc.part, ssc.part_floats, sd));
   if (d_z) {
     DVAE_TRY(g.nn(w.DH0, HP, P + L.Wl1, d.ZP, w.DZP, d.ZP, B, d.ZP, HP));
     DVAE_TRY(k_unpad_rows(w.DZP, d.ZP, B, d.Z, d_z, st));
