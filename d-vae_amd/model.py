@@ -270,27 +270,35 @@ class Dvae(nn.Module):
     def test_dataloader(self):
         return self.test_loader
 
-    def predict(self, X):
+    def predict(self, X, eps=None, return_margin=False):
+        """:492-496.  ``eps`` [B,Z] (optional) replaces the reparameterisation draw (parity tests: device
+        and CPU generators cannot match)."""
         with torch.no_grad():
             _, mu, logvar = self.encoder.predict(X)
-            z = self.reparamterize(mu, logvar)
-        return self.decoder.predict(z)
+            z = self.reparamterize(mu, logvar, eps)
+        return self.decoder.predict(z, return_margin=return_margin)
 
-    def model_eval(self, X, sample_num, decode_num, is_stochastic=True):
+    def model_eval(self, X, sample_num, decode_num, is_stochastic=True, eps=None, uniforms=None, return_decoded=False):
+        """:498-524.  ``eps`` [B,sample_num,Z] replaces the reparameterisation draw, ``uniforms`` =
+        (u_type [B*S*D,N], u_edge [B*S*D,N,N]) the decoder's draws (stochastic mode); both optional.
+        ``return_decoded`` adds the decoded tensors [B, D*S, N, .] to the result."""
         with torch.no_grad():
             _, mu, logvar = self.encoder.predict(X)
             stack_mu = torch.stack([mu] * sample_num, dim=1)
             stack_logvar = torch.stack([logvar] * sample_num, dim=1)
-            stack_z = self.reparamterize(stack_mu, stack_logvar)
+            stack_z = self.reparamterize(stack_mu, stack_logvar, eps)
             batch_size, samples, hidden_size = stack_z.shape
             assert samples == sample_num
             stack_z = stack_z.repeat(1, decode_num, 1)
             sampled_z = stack_z.view(batch_size * sample_num * decode_num, hidden_size)
-            gen_edges, gen_nodes = self.decoder.predict(sampled_z, is_stochastic)
+            gen_edges, gen_nodes = self.decoder.predict(sampled_z, is_stochastic, uniforms=uniforms)
             gen_edges = gen_edges.view(batch_size, decode_num * sample_num, *gen_edges.shape[1:])
             gen_nodes = gen_nodes.view(batch_size, decode_num * sample_num, *gen_nodes.shape[1:])
             recon_acc = reconstruction_accuracy(X['node_encoding'], X['graph'], gen_nodes, gen_edges)
-            return {'recon_acc': recon_acc}
+            out = {'recon_acc': recon_acc}
+            if return_decoded:
+                out['gen_edges'], out['gen_nodes'] = gen_edges, gen_nodes
+            return out
 
     def generation_eval(self, num_samples=None, z=None, train_batch=None, is_stochastic=False, task_type='enas',
                         dist=None):

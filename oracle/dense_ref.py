@@ -274,6 +274,42 @@ def decoder_predict(sd, z, N, C, mod=None, uniforms=None, return_margin=False):
 
 
 # --------------------------------------------------------------------------
+# model-level decode paths (dvae_model.py:492-524) and the metric (dvae/utils/metrics.py:4-28)
+# --------------------------------------------------------------------------
+def reconstruction_accuracy(true_enc, true_deps, pred_enc, pred_deps):
+    """metrics.py:4-28: fraction of decoded graphs whose node types (:18-21) AND adjacency (:24-25)
+    equal the input's; pred_* carry a sample axis [B,S,N,.]."""
+    B, S = pred_enc.shape[0], pred_enc.shape[1]
+    node_eq = (true_enc.unsqueeze(1) == pred_enc).all(dim=-1).all(dim=-1)
+    edge_eq = (true_deps.unsqueeze(1) == pred_deps).all(dim=-1).all(dim=-1) & node_eq
+    return int(edge_eq.sum()) / (B * S)
+
+
+def model_predict(sd, g, x, eps, mod=None, bidirectional=False):
+    """Dvae.predict (:492-496) with eps injected: encode -> reparameterise -> greedy decode."""
+    _, mu, logvar = encoder_forward(sd, g, x, mod, bidirectional)
+    z = reparameterize(mu, logvar, eps)
+    return decoder_predict(sd, z, g.shape[1], x.shape[2], mod)
+
+
+def model_eval(sd, g, x, eps, sample_num, decode_num, mod=None, bidirectional=False, uniforms=None):
+    """Dvae.model_eval (:498-524): eps [B,sample_num,Z]; z rows are laid out as
+    stack_z.repeat(1, decode_num, 1).view(B*S*D, Z) (:506-508), i.e. row = (b, d, s).
+    Greedy when uniforms is None, else stochastic with injected uniforms (decoder_predict).
+    Returns (recon_acc, gen_edges [B,D*S,N,N], gen_nodes [B,D*S,N,C], z rows)."""
+    B, N, C = g.shape[0], g.shape[1], x.shape[2]
+    _, mu, logvar = encoder_forward(sd, g, x, mod, bidirectional)
+    stack_mu = torch.stack([mu] * sample_num, dim=1)                  # :501
+    stack_logvar = torch.stack([logvar] * sample_num, dim=1)          # :502
+    stack_z = reparameterize(stack_mu, stack_logvar, eps)             # :503
+    z = stack_z.repeat(1, decode_num, 1).reshape(B * sample_num * decode_num, -1)   # :506-508
+    e, t = decoder_predict(sd, z, N, C, mod, uniforms=uniforms)
+    e = e.view(B, decode_num * sample_num, N, N)                       # :512-515
+    t = t.view(B, decode_num * sample_num, N, C)
+    return reconstruction_accuracy(x, g, t, e), e, t, z
+
+
+# --------------------------------------------------------------------------
 # ragged batches: outside the reference (it forces N == max_seq, :60-62).
 # Oracle per SURVEY.md section 5: group graphs by size n and run the dense path on
 # [n,n] blocks; position one-hots of nodes < n only touch the first n position

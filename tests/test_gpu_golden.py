@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from helpers import close_scaled
-from test_oracle_golden import GOLD, TRAIN_CASES, build_model, load_case
+from test_oracle_golden import EVAL_CASES, GOLD, TRAIN_CASES, build_model, eval_model, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -65,3 +65,58 @@ def test_hip_greedy_decode_bit_exact(cuda, name):
     assert keep.sum() >= 40
     assert np.array_equal(edges.cpu().numpy()[keep], d['edges'][keep])
     assert np.array_equal(types.cpu().numpy()[keep], d['types'][keep])
+
+
+@pytest.mark.parametrize("name", EVAL_CASES)
+def test_hip_model_predict_and_eval_match_reference(cuda, name):
+    """Dvae.predict (:492-496) and greedy Dvae.model_eval (:498-524) against the real reference's outputs
+    with the same injected eps: decoded adjacency / types bit-exact on every row whose recorded decision
+    margin is above fp32 noise, recon_acc equal up to the rows that are not."""
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    model, mod, bidir = eval_model(d, cuda)
+    S, D = int(d['S']), int(d['D'])
+    X = {'graph': torch.from_numpy(d['g']).to(cuda), 'node_encoding': torch.from_numpy(d['x']).to(cuda)}
+    edges, types = model.predict(X, eps=torch.from_numpy(d['eps_predict']).to(cuda))
+    keep = d['predict_margins'] > 2e-3
+    assert keep.sum() >= 3
+    assert np.array_equal(edges.cpu().numpy()[keep], d['predict_edges'][keep])
+    assert np.array_equal(types.cpu().numpy()[keep], d['predict_types'][keep])
+    eps = torch.from_numpy(d['eps_eval']).to(cuda)
+    for tag, Xc in (("eval1", X), ("eval2", {'graph': torch.from_numpy(d['g2']).to(cuda),
+                                              'node_encoding': torch.from_numpy(d['x2']).to(cuda)})):
+        out = model.model_eval(Xc, S, D, is_stochastic=False, eps=eps, return_decoded=True)
+        B = Xc['graph'].shape[0]
+        safe = (d[tag + '_margins'] > 2e-3).reshape(B, D * S)
+        ge, gt = out['gen_edges'].cpu().numpy(), out['gen_nodes'].cpu().numpy()
+        assert np.array_equal(ge[safe], d[tag + '_edges'][safe]) and np.array_equal(gt[safe], d[tag + '_types'][safe])
+        unsafe = int((~safe).sum())
+        assert abs(out['recon_acc'] - float(d[tag + '_acc'])) <= unsafe / safe.size + 1e-12, (tag, out['recon_acc'])
+        if unsafe == 0:
+            assert out['recon_acc'] == float(d[tag + '_acc'])
+    # recon_acc restricted to the safe rows is exactly the reference's on those rows
+    ref_ok = ((d['eval2_edges'] == d['g2'][:, None]).all((2, 3)) & (d['eval2_types'] == d['x2'][:, None]).all((2, 3)))
+    got_ok = ((ge == d['g2'][:, None]).all((2, 3)) & (gt == d['x2'][:, None]).all((2, 3)))
+    assert np.array_equal(ref_ok[safe], got_ok[safe]) and ref_ok[safe].sum() > 0
+
+
+def test_hip_model_eval_stochastic_injected_uniforms(cuda):
+    """Stochastic Dvae.model_eval: the reference draws with torch.multinomial / torch.bernoulli (:285,314),
+    which no injected stream can reproduce, so this mode is pinned at the oracle (inverse-CDF type draw,
+    u < sigmoid edge draw) -- whose greedy mode equals the reference bit for bit (test above)."""
+    from helpers import oracle_sd
+    from oracle import dense_ref as O
+    d = np.load(os.path.join(GOLD, "eval_none_bidir.npz"))
+    model, mod, bidir = eval_model(d, cuda)
+    S, D = int(d['S']), int(d['D'])
+    g, x = torch.from_numpy(d['g']), torch.from_numpy(d['x'])
+    B, N = g.shape[0], g.shape[1]
+    gen = torch.Generator().manual_seed(5)
+    u = {'type': torch.rand(B * S * D, N, generator=gen), 'edge': torch.rand(B * S * D, N, N, generator=gen)}
+    eps = torch.from_numpy(d['eps_eval'])
+    with torch.no_grad():
+        o_acc, o_e, o_t, _ = O.model_eval(oracle_sd(model), g, x, eps, S, D, mod, bidir, uniforms=u)
+    out = model.model_eval({'graph': g.to(cuda), 'node_encoding': x.to(cuda)}, S, D, is_stochastic=True,
+                           eps=eps.to(cuda), uniforms=(u['type'].to(cuda), u['edge'].to(cuda)), return_decoded=True)
+    same = ((out['gen_edges'].cpu() == o_e).flatten(2).all(2) & (out['gen_nodes'].cpu() == o_t).flatten(2).all(2))
+    assert int((~same).sum()) <= 2, "stochastic model_eval differs on %d/%d rows" % (int((~same).sum()), same.numel())
+    assert abs(out['recon_acc'] - o_acc) <= int((~same).sum()) / same.numel() + 1e-12

@@ -29,10 +29,22 @@ def build_model(d, mod, bidir, shared, device=None):
     return model.to(device) if device is not None else model
 
 
+EVAL_CASES = ["eval_none_bidir", "eval_bn"]       # tests/golden/make_eval_golden.py
+
+
+def eval_model(d, device=None):
+    import dvae_amd
+    mod = None if str(d['mod']) == 'None' else str(d['mod'])
+    N, C = d['x'].shape[1], d['x'].shape[2]
+    hp = Namespace(dataset_file=None, mod=mod, bidirectional=bool(d['bidir']), num_classes=C, max_seq=N)
+    model = fill_weights(dvae_amd.Dvae(hp), int(d['seed']))
+    return (model.to(device) if device is not None else model), mod, bool(d['bidir'])
+
+
 def test_fixture_inventory():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
     svae = ["svae_enas_val8_uni", "svae_enas_val8_bidir", "svae_rand10_bidir"]      # test_svae_oracle.py
-    assert names == sorted(TRAIN_CASES + ["predict_none", "predict_bn", "enas_rows"] + svae)
+    assert names == sorted(TRAIN_CASES + ["predict_none", "predict_bn", "enas_rows", "bn_rows"] + EVAL_CASES + svae)
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -113,3 +125,52 @@ def test_dataset_parser_and_split(tmp_path):
     assert isinstance(va, tuple) and len(va) == 1
     b = next(iter(tr))
     assert b['graph'].shape == (2, 8, 8) and b['node_encoding'].shape == (2, 8, 8) and b['acc'].dtype == torch.float64
+
+
+@pytest.mark.parametrize("name", EVAL_CASES)
+def test_oracle_model_predict_and_eval_match_reference(name):
+    """Dvae.predict (:492-496) and greedy Dvae.model_eval (:498-524) of the reference, eps injected:
+    decoded tensors and recon_acc, on real rows and on the fed-back decodes (non-zero accuracy)."""
+    from oracle import dense_ref as O
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    model, mod, bidir = eval_model(d)
+    sd = oracle_sd(model)
+    g, x = torch.from_numpy(d['g']), torch.from_numpy(d['x'])
+    S, D = int(d['S']), int(d['D'])
+    with torch.no_grad():
+        e, t = O.model_predict(sd, g, x, torch.from_numpy(d['eps_predict']), mod, bidir)
+        assert np.array_equal(e.numpy(), d['predict_edges']) and np.array_equal(t.numpy(), d['predict_types'])
+        acc, ee, tt, _ = O.model_eval(sd, g, x, torch.from_numpy(d['eps_eval']), S, D, mod, bidir)
+        assert acc == float(d['eval1_acc'])
+        assert np.array_equal(ee.numpy(), d['eval1_edges']) and np.array_equal(tt.numpy(), d['eval1_types'])
+        acc2, ee2, tt2, _ = O.model_eval(sd, torch.from_numpy(d['g2']), torch.from_numpy(d['x2']),
+                                         torch.from_numpy(d['eps_eval']), S, D, mod, bidir)
+        assert acc2 == float(d['eval2_acc']) and 0.0 < acc2 < 1.0
+        assert np.array_equal(ee2.numpy(), d['eval2_edges']) and np.array_equal(tt2.numpy(), d['eval2_types'])
+    # the product's metric (torch, not a kernel) on the reference's decodes gives the reference's number
+    from dvae_amd import reconstruction_accuracy
+    assert reconstruction_accuracy(torch.from_numpy(d['x2']), torch.from_numpy(d['g2']),
+                                   torch.from_numpy(d['eval2_types']), torch.from_numpy(d['eval2_edges'])) == float(d['eval2_acc'])
+
+
+def test_bn_dataset_parser_and_split(tmp_path):
+    """d-vae_amd/data.py in task_type='bn' against the reference's NASDataset(task_type='bn')
+    (dataloader.py:17-26,57-88) on synthetic BN rows (the reference ships no BN data): every split index,
+    adjacency / one-hot encoding (no chain edge in 'bn', :82-84), score column, string form."""
+    from dvae_amd import data
+    r = np.load(os.path.join(GOLD, "bn_rows.npz"))
+    f = tmp_path / "bn.txt"
+    f.write_text("\n".join(str(l) for l in r['lines']) + "\n")
+    for split in ('train', 'val', 'test'):
+        ds = data.NASDataset(str(f), split=split, task_type='bn')
+        assert np.array_equal(ds.index, r[split + '_index'])
+    ds = data.NASDataset(str(f), split='val', task_type='bn')
+    for i in range(len(ds)):
+        it = ds[i]
+        assert it['graph'].shape == (10, 10) and it['node_encoding'].shape == (10, 10)
+        assert np.array_equal(it['graph'].numpy(), r['val_graph'][i])
+        assert np.array_equal(it['node_encoding'].numpy(), r['val_node_encoding'][i])
+        assert it['acc'] == r['val_acc'][i]
+    ds = data.NASDataset(str(f), split='val', fmt='str', task_type='bn')
+    for i in range(len(ds)):
+        assert np.array_equal(ds[i]['graph'].numpy(), r['val_str'][i])
