@@ -42,7 +42,7 @@ constexpr size_t GEMM_WS_BYTES = (size_t)96 << 20;
 
 size_t part_floats_for(const dvae_dims& d) {
   size_t m = (size_t)(d.EHP + 4) * (2048 + 64);   // pair_bwd_a: one partial per wave + the group sums of its 2-stage reduction
-  m = std::max(m, (size_t)(2 * d.EHP + 4) * (1024 + 40));   // pair_bwd_fused: [db1 | dw2 | db2] per block
+  m = std::max(m, (size_t)(2 * d.EHP + 4) * (2048 + 80));   // pair_bwd_fused / pair_bwd_win: [db1 | dw2 | db2] per block
   m = std::max(m, (size_t)d.EHP * 512);
   return m;
 }
@@ -809,10 +809,17 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   const TypeShare ts{typed ? w.AT : nullptr, z1};
   const bool scored = scored_rows_only(), skip0 = skip_level0(info);
   const int U = (scored && lv.as[d.N] <= lv.E) ? lv.as[d.N] : -1;   // scored edge rows (sv.a_rows), -1: all rows
-  if (pair_bwd_fused_ok(d.N, EHP)) {
-    // its partial sums carry db1 (the column sums of DBq), dw2 and db2, adjacent in the packed layout
+  // one-pass backward of the pair scorer: small graphs keep every candidate's accumulator on chip, larger
+  // ones walk the candidates in register-resident windows; both also sum db1 (the column sums of DBq)
+  const bool pair_one_pass = pair_bwd_fused_ok(d.N, EHP) || pair_bwd_win_ok(EHP);
+  if (pair_one_pass) {
+    // its partial sums carry db1, dw2 and db2, adjacent in the packed layout
     DVAE_REQUIRE(L.w2 == L.b1 + (size_t)EHP && L.b2 == L.w2 + (size_t)EHP, "decoder layout: b1 | w2 | b2 must be adjacent");
-    DVAE_TRY(k_pair_bwd_fused(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.b1, msc.part,
+    if (pair_bwd_fused_ok(d.N, EHP))
+      DVAE_TRY(k_pair_bwd_fused(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.b1, msc.part,
+                                msc.part_floats, EHP, st));
+    else
+      DVAE_TRY(k_pair_bwd_win(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, w.DBq, Gp + L.b1, msc.part,
                               msc.part_floats, EHP, st));
   } else {
     DVAE_TRY(k_pair_bwd_a(sv, ts, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part,
@@ -838,7 +845,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   }
   const int Rb = bq_rows(info, lv);   // DBq rows beyond Rb are zero (no pair has them as candidate)
   DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, Rb));
-  if (!pair_bwd_fused_ok(d.N, EHP))   // (the fused pair backward has summed db1 already)
+  if (!pair_one_pass)   // (the one-pass pair backward has summed db1 already)
     DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
   if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
 

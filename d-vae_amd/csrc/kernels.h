@@ -126,6 +126,12 @@ bool pair_bwd_fused_ok(int N, int EHP);
 int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A,
                      const float* Bq, const float* Cq, const float* w2, const float* d_edge, float* DA, float* DBq,
                      float* out, float* part, size_t part_floats, int EHP, hipStream_t st);
+// the same for graphs of any size: candidates walked in register-resident windows (pair_bwd_win_ok: widths
+// that are whole groups of 1024 columns)
+bool pair_bwd_win_ok(int EHP);
+int k_pair_bwd_win(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A,
+                   const float* Bq, const float* Cq, const float* w2, const float* d_edge, float* DA, float* DBq,
+                   float* out, float* part, size_t part_floats, int EHP, hipStream_t st);
 // out[b] = sum over the graph's nodes of T[row]   (W % 4 == 0)
 int k_graph_sum(const SchedDir& S, const int* sizes, int B, int N, const float* T, int W, float* out,
                 hipStream_t st);

@@ -1150,6 +1150,122 @@ __global__ __launch_bounds__(256) void pair_bwd_fused_kernel(SchedView sv, TypeS
   if (threadIdx.x == 0) st4(out + 2 * EHP, make_float4(db, 0.f, 0.f, 0.f));
 }
 
+// Fused backward of the pair scorer for LARGER graphs (N > 8: the candidates' accumulators no longer fit
+// in registers or LDS at once): the candidate nodes are walked in windows of WIN.  A work item is
+// (graph, group of 1024 columns); its 256 threads own one float4 of columns each, so -- as in
+// pair_bwd_fused_kernel -- no thread ever needs another thread's data and nothing is reduced across lanes.
+// Per window the thread keeps Bq[j] and dL/dBq[j] of the WIN candidates in registers and walks every
+// later node's prefix rows that meet the window: an A row is read once per window it meets (once per
+// pair in pair_bwd_a / pair_bwd_b, which also read a Bq row per pair), and dL/dA of a row that spans
+// several windows is accumulated in place (same thread, same columns: program order, no atomics).
+template <int WIN>
+__global__ __launch_bounds__(256) void pair_bwd_win_kernel(SchedView sv, TypeShare ts, int R, int EHP, int G,
+                                                           const int* __restrict__ sizes,
+                                                           const float* __restrict__ A,
+                                                           const float* __restrict__ Bq,
+                                                           const float* __restrict__ Cq,
+                                                           const float* __restrict__ w2,
+                                                           const float* __restrict__ d_edge,
+                                                           float* __restrict__ DA, float* __restrict__ DBq,
+                                                           float* __restrict__ part) {
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N, B = sv.B;
+  // gridDim.x is a multiple of G: a block keeps its column group over its grid-stride loop
+  const int cg = blockIdx.x % G;
+  const int col = cg * 1024 + threadIdx.x * 4;
+  const float4 wv = ld4(w2 + col);
+  float4 dw = zero4(), dbs = zero4();
+  float db = 0.f;
+  for (long long w = blockIdx.x; w < (long long)B * G; w += gridDim.x) {
+    const int b = (int)(w / G);
+    const int n = graph_size(sizes, b, N);
+    const float4 c = Cq ? ld4(Cq + (size_t)b * EHP + col) : zero4();
+    // rows that no pair is scored on: node 0's row, and a full prefix whose lowest predecessor is node 0
+    for (int i = 0; i < n; ++i) {
+      const int r = S.node2row[b * N + i];
+      const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+      if (i == 0) st4(DA + (size_t)prow_of(S, R, r, 0) * EHP + col, zero4());
+      else if (deg > 0 && S.row_node[S.csr_idx[p + deg - 1]] == 0) st4(DA + (size_t)prow_of(S, R, r, deg) * EHP + col, zero4());
+    }
+    for (int jb = 0; jb + 1 < n; jb += WIN) {
+      float4 bq[WIN], dj[WIN];
+#pragma unroll
+      for (int jj = 0; jj < WIN; ++jj) {
+        dj[jj] = zero4();
+        const int j = jb + jj;
+        bq[jj] = j < n ? ld4(Bq + (size_t)S.node2row[b * N + j] * EHP + col) : zero4();
+      }
+      for (int i = jb + 1; i < n; ++i) {
+        const int r = S.node2row[b * N + i];
+        const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+        const float* de = d_edge + ((size_t)b * N + i) * N;
+        // prefix index of the highest candidate of this window that node i is paired with
+        const int jtop = min(jb + WIN, i) - 1;
+        int t = 0;
+        while (t < deg && S.row_node[S.csr_idx[p + t]] > jtop) ++t;
+        int next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
+        int cur = -1;
+        float4 a = zero4(), da = zero4();
+        auto flush = [&]() {   // row (i, cur) leaves the window: its first window sets, later ones add
+          if (cur < 0) return;
+          float* dst = DA + (size_t)prow_of(S, R, r, cur) * EHP + col;
+          const int lo = cur < deg ? S.row_node[S.csr_idx[p + cur]] : 0;   // lowest candidate of the row
+          st4(dst, lo >= jb ? da : add4(ld4(dst), da));
+        };
+#pragma unroll
+        for (int jj = WIN - 1; jj >= 0; --jj) {
+          const int j = jb + jj;
+          if (j > jtop) continue;
+          while (t < deg && next_pred > j) {
+            ++t;
+            next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
+          }
+          if (t != cur) {
+            flush();
+            a = add4(ld4(a_row(sv, ts, A, EHP, R, r, t) + col), c);
+            da = zero4();
+            cur = t;
+          }
+          const float ds = de[j];
+          const float4 x = add4(a, bq[jj]);
+#define PW_LANE(f)                                   \
+          if (x.f > 0.f) {                           \
+            const float u = ds * wv.f;               \
+            da.f += u;                               \
+            dj[jj].f += u;                           \
+            dw.f = fmaf(ds, x.f, dw.f);              \
+          }
+          PW_LANE(x) PW_LANE(y) PW_LANE(z) PW_LANE(w)
+#undef PW_LANE
+          if (cg == 0) db += ds;
+        }
+        flush();
+      }
+#pragma unroll
+      for (int jj = 0; jj < WIN; ++jj) {
+        const int j = jb + jj;
+        if (j < n) {
+          st4(DBq + (size_t)S.node2row[b * N + j] * EHP + col, dj[jj]);
+          dbs = add4(dbs, dj[jj]);
+        }
+      }
+    }
+    if (n >= 1 && ((n - 1) % WIN) == 0) {
+      // the last node opens no window of its own when n-1 is a multiple of WIN: it is never a candidate
+      // (dvae_model.py:210), its dL/dBq row is zero
+      st4(DBq + (size_t)S.node2row[b * N + n - 1] * EHP + col, zero4());
+    }
+  }
+  // one partial row per block, [db1 | dw2 | db2] as the packed gradient has them; zeros in the columns of
+  // the other column groups
+  float* out = part + (size_t)blockIdx.x * (2 * EHP + 4);
+  for (int g = 0; g < EHP / 1024; ++g) {
+    st4(out + g * 1024 + threadIdx.x * 4, g == cg ? dbs : zero4());
+    st4(out + EHP + g * 1024 + threadIdx.x * 4, g == cg ? dw : zero4());
+  }
+  if (threadIdx.x == 0) st4(out + 2 * EHP, make_float4(db, 0.f, 0.f, 0.f));
+}
+
 #define VPL_DISPATCH(EHP, CALL)                                                   \
   switch ((EHP) / 256) {                                                          \
     case 1: { constexpr int V = 1; CALL; } break;                                 \
@@ -1460,6 +1576,35 @@ int k_pair_bwd_fused(const SchedView& sv, const TypeShare& ts, int R, const int*
   DVAE_LAUNCH_CHECK();
   const size_t used = (size_t)grid * per;
   return reduce_parts_2stage(part, grid, per, part + used, part_floats - used, out, per, st);
+}
+
+// true when k_pair_bwd_win covers this width (whole groups of 1024 columns)
+bool pair_bwd_win_ok(int EHP) {
+  static const bool off = getenv("DVAE_NO_PAIR_WIN") != nullptr;   // A-B tests: the two-kernel backward instead
+  return !off && EHP >= 1024 && EHP % 1024 == 0;
+}
+
+int k_pair_bwd_win(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A,
+                   const float* Bq, const float* Cq, const float* w2, const float* d_edge, float* DA, float* DBq,
+                   float* out, float* part, size_t part_floats, int EHP, hipStream_t st) {
+  if (R <= 0) return DVAE_OK;
+  const int G = EHP / 1024;
+  const size_t per = (size_t)2 * EHP + 4;   // [db1 | dw2 | db2], contiguous in the packed gradient too
+  static const int cap = getenv("DVAE_PAIR_WIN_GRID") ? atoi(getenv("DVAE_PAIR_WIN_GRID")) : 2048;   // lab
+  long long grid = std::min<long long>((long long)sv.B * G, cap);
+  grid = std::min<long long>(grid, (long long)(part_floats / per * 32 / 33));   // room for the 2-stage reduction's group sums
+  grid = grid / G * G;                       // a block keeps one column group
+  DVAE_REQUIRE(grid >= G, "pair_bwd_win: scratch too small");
+  static const int win = getenv("DVAE_PAIR_WIN") ? atoi(getenv("DVAE_PAIR_WIN")) : 8;   // lab: candidates per window (8: 119 VGPRs, 16: 185; same-box c3 129.6 vs 131.5 ms)
+  if (win == 8)
+    hipLaunchKernelGGL((pair_bwd_win_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, sv, ts, R, EHP, G, sizes, A, Bq, Cq,
+                       w2, d_edge, DA, DBq, part);
+  else
+    hipLaunchKernelGGL((pair_bwd_win_kernel<16>), dim3((unsigned)grid), dim3(256), 0, st, sv, ts, R, EHP, G, sizes, A, Bq,
+                       Cq, w2, d_edge, DA, DBq, part);
+  DVAE_LAUNCH_CHECK();
+  const size_t used = (size_t)grid * per;
+  return reduce_parts_2stage(part, (int)grid, per, part + used, part_floats - used, out, per, st);
 }
 
 int k_pair_bwd_b(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,

@@ -243,3 +243,55 @@ torch.save(out, sys.argv[1])
         torch.cuda.synchronize()
         assert torch.equal(o4.cpu(), other[bidir][0])
         assert all(torch.equal(p.grad.cpu(), v) for p, v in zip(model.parameters(), other[bidir][1]))
+
+
+def test_windowed_pair_backward_matches_two_kernel_form(cuda, tmp_path):
+    """Graphs beyond 8 nodes: the one-pass windowed pair backward (default, 8 candidates per window)
+    against the same kernel with 16 per window and against the two-kernel form (DVAE_NO_PAIR_WIN=1), each in
+    a child process (the switches are read once per process): ragged 30-node graphs at hs=501 and
+    Bayesian-network graphs (three column groups), every gradient within fp32 reorder noise; dL/dBq and
+    dL/dA sums are per-thread and fixed-order in all forms, only the order within a row differs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = '''
+import sys, torch
+from argparse import Namespace
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import dvae_amd
+from helpers import fill_weights
+dev = torch.device("cuda")
+def run():
+    out = {}
+    for name, mod, N, C in (("none", None, 30, 6), ("bn", "bn", 10, 10)):
+        hp = Namespace(dataset_file=None, mod=mod, bidirectional=False, num_classes=C, max_seq=N)
+        model = fill_weights(dvae_amd.Dvae(hp), 5).to(dev)
+        if mod is None:
+            g, x, sizes = dvae_amd.synth.ragged_dags(24, C, 3, nmin=9, nmax=N)
+            X = {"graph": g.to(dev), "node_encoding": x.to(dev), "sizes": sizes.to(dev)}
+        else:
+            g, x = dvae_amd.synth.random_dags(40, N, C, 0.3, 4, fix_orphans=False)
+            X = {"graph": g.to(dev), "node_encoding": x.to(dev)}
+        eps = torch.randn(g.shape[0], 56, generator=torch.Generator().manual_seed(1))
+        o4 = model.loss_and_grad(X, eps=eps.to(dev))
+        torch.cuda.synchronize()
+        out[name] = (o4.cpu(), [p.grad.cpu().clone() for p in model.parameters()])
+    return out
+''' % (root, os.path.join(root, "tests"))
+    script = tmp_path / "run.py"
+    script.write_text(body + "torch.save(run(), sys.argv[1])\n")
+    assert "DVAE_NO_PAIR_WIN" not in os.environ and "DVAE_PAIR_WIN" not in os.environ
+    others = {}
+    for tag, env in (("two_kernel", {"DVAE_NO_PAIR_WIN": "1"}), ("win16", {"DVAE_PAIR_WIN": "16"})):
+        path = str(tmp_path / (tag + ".pt"))
+        subprocess.run([sys.executable, str(script), path], check=True, env=dict(os.environ, **env), timeout=400)
+        others[tag] = torch.load(path, weights_only=True)
+    ns = {}
+    exec(compile(body, "run_body", "exec"), ns)
+    mine = ns["run"]()
+    for tag, other in others.items():
+        for name in ("none", "bn"):
+            assert torch.allclose(mine[name][0], other[name][0], rtol=1e-6), (tag, name)
+            for a, b in zip(mine[name][1], other[name][1]):
+                close_scaled(a, b, tol=2e-5, what="%s/%s gradient" % (tag, name))
