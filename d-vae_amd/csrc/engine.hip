@@ -827,27 +827,38 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     DVAE_TRY(k_pair_bwd_b(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
   }
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
-  DVAE_TRY(ev.edge(st, sd));
-  if (typed) {
-    // type-shared rows [z1,R): their gradients meet in the per-type sums DTT = DA^T . onehot(type)
-    //   d hv(type) = DTT^T . W1a  -> GRU backward once per type (k_type_gru_bwd)
-    //   dW1a      += DTT . hv(type)
-    DVAE_TRY(k_build_xp(S, 1, RH, x, d.N, d.C, w.s.XP, sd));
-    DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
-    DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
-    DVAE_TRY(k_type_gru_bwd(d.C, sw.gru, w.DTV, w.TG, w.TGN, w.XPT, HP, sd));
-    if (U >= 0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, U, 0, sv.a_rows));
-    else DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R));
-    if (!skip0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1, 1));
-    DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
-  } else {
-    DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
-  }
+  // the add_edge weight-gradient products (side stream).  Lab switch: issue them AFTER the chain's own
+  // add_edge input-gradient products, so that those two -- the largest launches on the chain (B=512: 219 +
+  // 80 us beside the side stream's products, 111 + 40 us alone) -- run alone.  Measured neutral (B=512: 2.613
+  // vs 2.618 ms, B=1024: 3.96 vs 3.92, same box): what the chain gains there the sweep behind it loses to
+  // the deferred products.  Off by default; DVAE_DEFER_SIDE_ROWS=<node rows below which they are deferred>.
+  static const int defer_rows = getenv("DVAE_DEFER_SIDE_ROWS") ? atoi(getenv("DVAE_DEFER_SIDE_ROWS")) : 0;
+  const bool defer_side = sd != st && R < defer_rows;
   const int Rb = bq_rows(info, lv);   // DBq rows beyond Rb are zero (no pair has them as candidate)
-  DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, Rb));
-  if (!pair_one_pass)   // (the one-pass pair backward has summed db1 already)
-    DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
-  if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
+  auto side_products = [&]() -> int {
+    DVAE_TRY(ev.edge(st, sd));
+    if (typed) {
+      // type-shared rows [z1,R): their gradients meet in the per-type sums DTT = DA^T . onehot(type)
+      //   d hv(type) = DTT^T . W1a  -> GRU backward once per type (k_type_gru_bwd)
+      //   dW1a      += DTT . hv(type)
+      DVAE_TRY(k_build_xp(S, 1, RH, x, d.N, d.C, w.s.XP, sd));
+      DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
+      DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
+      DVAE_TRY(k_type_gru_bwd(d.C, sw.gru, w.DTV, w.TG, w.TGN, w.XPT, HP, sd));
+      if (U >= 0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, U, 0, sv.a_rows));
+      else DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R));
+      if (!skip0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1, 1));
+      DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
+    } else {
+      DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, RH));
+    }
+    DVAE_TRY(gs.tn(w.DBq, EHP, w.s.Hn, HP, Gp + L.W1b, HP, EHP, HP, Rb));
+    if (!pair_one_pass)   // (the one-pass pair backward has summed db1 already)
+      DVAE_TRY(k_colsum(w.DBq, EHP, R, EHP, Gp + L.b1, ssc.part, ssc.part_floats, sd));
+    if (d.mod) DVAE_TRY(gs.tn(w.DCq, EHP, w.H0, HP, Gp + L.W1c, HP, EHP, HP, B));
+    return DVAE_OK;
+  };
+  if (!defer_side) DVAE_TRY(side_products());
 
   // ---- add_edge input gradients, then the level sweep ----
   // (measured and dropped: producing dA.W1a / dBq.W1b level by level just ahead of the sweep and
@@ -874,6 +885,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(k_zero(w.DH0, (size_t)B * HP * 4, st));
   DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, Rb, HP, EHP, 1));
+  if (defer_side) DVAE_TRY(side_products());
   const TypeGrad tgrad{w.TG, w.TGN, w.XPT};
   DVAE_TRY(sweep_bwd_wgrad(d, S, lv, w.s, sw, x, WgradOut{Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm}, true,
                            g, gs, ev, typed, typed ? &tgrad : nullptr));

@@ -245,12 +245,12 @@ class ParamPack:
         self.P = torch.zeros(self.nfloats, dtype=torch.float32, device=dev)
 
     def pack(self, dims, params):
-        for p in params:
-            _require_cuda(p, "parameter")
-            assert p.dtype == torch.float32 and p.is_contiguous(), "parameters must be contiguous fp32"
         shape = tuple(getattr(dims, f) for f, _ in dims._fields_ if f not in ("B", "T"))   # batch-independent fields
         key = shape + tuple(p.data_ptr() for p in params)
         if key != self.key:
+            for p in params:      # (a tensor keeps dtype and strides for as long as it keeps its storage)
+                _require_cuda(p, "parameter")
+                assert p.dtype == torch.float32 and p.is_contiguous(), "parameters must be contiguous fp32"
             self._build(dims, params)
             self.key = key
         check(load().dvae_pack_params(_ptr(self.table), self.n, _ptr(self.P), _stream()))

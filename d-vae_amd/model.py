@@ -320,15 +320,24 @@ class Dvae(nn.Module):
     # -- fused train step (no autograd graph) --------------------------------------
     def _flat_grads(self):
         """Persistent flat gradient buffers (one per module) with p.grad installed
-        as views, so a data-parallel all-reduce is one collective per buffer."""
+        as views, so a data-parallel all-reduce is one collective per buffer.
+        Returns (fe, fd, encoder views, decoder views); the views are made once per buffer."""
         enc_p, dec_p = self.encoder.hip_params(), self.decoder.hip_params()
         key = tuple(p.data_ptr() for p in enc_p + dec_p)
         if self._flat is None or self._flat[0] != key:
             dev = enc_p[0].device
             fe = torch.zeros(sum(p.numel() for p in enc_p), device=dev)
             fd = torch.zeros(sum(p.numel() for p in dec_p), device=dev)
-            self._flat = (key, fe, fd)
-        return self._flat[1], self._flat[2]
+            ve, vd, o = [], [], 0
+            for p in enc_p:
+                ve.append(fe[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            o = 0
+            for p in dec_p:
+                vd.append(fd[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            self._flat = (key, fe, fd, ve, vd)
+        return self._flat[1:]
 
     def prepare(self, batch, resident=False, on_side_stream=False):
         """Queue the level-schedule build of a FUTURE batch on a stream of its own and
@@ -351,13 +360,17 @@ class Dvae(nn.Module):
             stream.wait_stream(torch.cuda.current_stream())
         return E.Schedule(g, sizes, want_reverse=self.encoder.is_bidirectional, stream=stream, defer=True, x=x)
 
-    def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, sched=None):
+    def loss_and_grad(self, batch, eps=None, beta=0.005, grad_sync=None, sched=None, on_decoder_grads=None):
         """Forward + backward of training_step's loss without building an autograd
         graph: same kernels, gradients written straight into flat buffers whose
         views become ``p.grad``.  ``grad_sync(flat)`` (optional) is called as soon
         as a buffer is complete -- the decoder's while the encoder's backward is
         still running -- and may return a handle with ``.wait()``.  ``sched``: the
         result of ``prepare(batch)`` for this batch (built ahead of time).
+        ``on_decoder_grads()`` (optional) runs on the library's side stream as soon as the decoder's
+        gradients are final (all-reduced when ``grad_sync`` is given) and installed as ``p.grad`` -- e.g. the
+        decoder's optimizer step, which then overlaps the encoder's backward (not with same_mapper_gater,
+        whose shared gradients are complete only at the end).
         Returns the device tensor [edge_loss, vertex_loss, kl_loss, loss]."""
         g, x, sizes = _batch_parts(batch)
         self.encoder._check(g, x)
@@ -375,7 +388,7 @@ class Dvae(nn.Module):
             d_enc = E._dims_for(enc._dims, sched.B, sched.N)
             d_dec = E._dims_for(dec._dims, sched.B, sched.N)
             Pe = enc._pack.pack(d_enc, enc_p)
-            fe, fd = self._flat_grads()
+            fe, fd, ve, vd = self._flat_grads()
             side = E.side_stream(main.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):     # the decoder's weights are not needed before the encoder is through
@@ -398,8 +411,15 @@ class Dvae(nn.Module):
             d_z = dc.backward(ge, gt, Gd, side=side)
             with torch.cuda.stream(side):
                 dec._pack.unpack(Gd, fd)
-                if grad_sync is not None:
-                    handles.append(grad_sync(fd))
+                h = grad_sync(fd) if grad_sync is not None else None
+                if on_decoder_grads is not None and not self._shared_gm:
+                    if h is not None:
+                        h.wait()              # orders the side stream after the collective
+                    for p, v in zip(dec_p, vd):
+                        p.grad = v
+                    on_decoder_grads()
+                elif h is not None:
+                    handles.append(h)
             dmu, dlv = E.reparam_bwd(d_z, ec.logvar, eps)
             gmu.add_(dmu)
             glv.add_(dlv)
@@ -412,11 +432,10 @@ class Dvae(nn.Module):
             for h in handles:
                 if h is not None:
                     h.wait()
-            ev = enc._pack.views(fe, enc_p)
-            for p, v in zip(enc_p, ev):
+            for p, v in zip(enc_p, ve):
                 p.grad = v
-            owner = {id(p): v for p, v in zip(enc_p, ev)} if self._shared_gm else {}
-            for p, v in zip(dec_p, dec._pack.views(fd, dec_p)):
+            owner = {id(p): v for p, v in zip(enc_p, ve)} if self._shared_gm else {}
+            for p, v in zip(dec_p, vd):
                 if id(p) in owner:
                     # same_mapper_gater (:382-399): one gate/map network serves both modules; its gradient is
                     # the sum of the two modules' parts (each already all-reduced with its buffer)

@@ -295,3 +295,27 @@ def run():
             assert torch.allclose(mine[name][0], other[name][0], rtol=1e-6), (tag, name)
             for a, b in zip(mine[name][1], other[name][1]):
                 close_scaled(a, b, tol=2e-5, what="%s/%s gradient" % (tag, name))
+
+
+def test_decoder_optimizer_step_under_the_encoder_backward(cuda):
+    """loss_and_grad(on_decoder_grads=...): the decoder's Adam step issued on the side stream as soon as its
+    gradients are final gives the same parameters, bit for bit, as one Adam over everything after the step."""
+    import dvae_amd
+    hp = Namespace(dataset_file=None, mod=None, bidirectional=True, num_classes=8, max_seq=8, hidden_state_size=128)
+    g, x = dvae_amd.synth.enas_like(200, 9)
+    X = {'graph': g.to(cuda), 'node_encoding': x.to(cuda)}
+    eps = [torch.randn(200, 56, generator=torch.Generator().manual_seed(s)).to(cuda) for s in (1, 2, 3)]
+    a = fill_weights(dvae_amd.Dvae(hp), 6).to(cuda)
+    b = fill_weights(dvae_amd.Dvae(hp), 6).to(cuda)
+    opt_a = torch.optim.Adam(a.parameters(), lr=1e-3, fused=True)
+    opt_be = torch.optim.Adam(b.encoder.parameters(), lr=1e-3, fused=True)
+    opt_bd = torch.optim.Adam(b.decoder.parameters(), lr=1e-3, fused=True)
+    for e in eps:
+        la = a.loss_and_grad(X, eps=e)
+        opt_a.step()
+        lb = b.loss_and_grad(X, eps=e, on_decoder_grads=opt_bd.step)
+        opt_be.step()
+        assert torch.equal(la, lb)
+    torch.cuda.synchronize()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), k
