@@ -40,6 +40,19 @@ class PackEntry(ctypes.Structure):
                 ("g_off", ctypes.c_int64), ("g_ld", c_int), ("g_kind", c_int)]
 
 
+class DvaeStep(ctypes.Structure):
+    """Mirror of ``struct dvae_step``."""
+    _fields_ = [("d_enc", ctypes.POINTER(DvaeDims)), ("d_dec", ctypes.POINTER(DvaeDims)),
+                ("g", c_void_p), ("x", c_void_p), ("sizes", c_void_p),
+                ("sched", c_void_p), ("info_host", c_void_p),
+                ("enc_table", c_void_p), ("enc_n", c_int),
+                ("dec_table", c_void_p), ("dec_n", c_int),
+                ("Pe", c_void_p), ("Pd", c_void_p),
+                ("ws_enc", c_void_p), ("ws_dec", c_void_p), ("ws_step", c_void_p),
+                ("eps", c_void_p), ("beta", c_float),
+                ("Ge", c_void_p), ("Gd", c_void_p), ("out4", c_void_p)]
+
+
 class DvaeError(RuntimeError):
     pass
 
@@ -93,6 +106,9 @@ SIGNATURES = {
     "dvae_elbo_ws_bytes": (c_size_t, [c_int]),
     "dvae_elbo": (c_int, [_P(DvaeDims)] + [c_void_p] * 7 + [c_float] + [c_void_p] * 7),
     "dvae_elbo_static": (c_int, [_P(DvaeDims)] + [c_void_p] * 7 + [c_float] + [c_void_p] * 6),
+    "dvae_step_ws_bytes": (c_size_t, [_P(DvaeDims)]),
+    "dvae_step_part1": (c_int, [_P(DvaeStep), c_void_p, c_void_p]),
+    "dvae_step_part2": (c_int, [_P(DvaeStep), c_void_p, c_void_p]),
     "dvae_predict_ws_bytes": (c_size_t, [_P(DvaeDims)]),
     "dvae_decoder_predict": (c_int, [_P(DvaeDims)] + [c_void_p] * 9),
     "dvae_svae_dims_init": (c_int, [_P(SvaeDims)]),

@@ -943,3 +943,71 @@ extern "C" int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_sh
   g_level_cfg.type_share = type_share;
   return DVAE_OK;
 }
+
+// ===========================================================================
+// one fused train step behind two calls (the host glue of Dvae.loss_and_grad in C)
+// ===========================================================================
+namespace {
+struct StepWs {
+  float *mu, *logvar, *z, *edge_logits, *type_logits, *d_edge, *d_type, *d_mu, *d_logvar, *d_z, *dmu2, *dlv2;
+  void* elbo_part;
+  size_t bytes;
+};
+StepWs step_ws(const dvae_dims& d, void* base) {
+  StepWs w;
+  Carver c{(char*)base, 0};
+  const size_t B = d.B, N = d.N;
+  w.mu = c.f(B * d.Z); w.logvar = c.f(B * d.Z); w.z = c.f(B * d.Z);
+  w.edge_logits = c.f(B * N * N); w.type_logits = c.f(B * N * d.C);
+  w.d_edge = c.f(B * N * N); w.d_type = c.f(B * N * d.C);
+  w.d_mu = c.f(B * d.Z); w.d_logvar = c.f(B * d.Z); w.d_z = c.f(B * d.Z);
+  w.dmu2 = c.f(B * d.Z); w.dlv2 = c.f(B * d.Z);
+  w.elbo_part = c.f((dvae_elbo_ws_bytes(d.B) + 3) / 4);
+  w.bytes = c.off;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t dvae_step_ws_bytes(const dvae_dims* d) { return step_ws(*d, nullptr).bytes; }
+
+extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stream) {
+  DVAE_REQUIRE(s && s->d_enc && s->d_dec && s->g && s->x && s->sched && s->info_host && s->Pe && s->Pd && s->ws_enc &&
+                   s->ws_dec && s->ws_step && s->eps && s->Ge && s->Gd && s->out4 && s->enc_table && s->dec_table,
+               "step_part1: null pointer");
+  const dvae_dims& de = *s->d_enc;
+  const dvae_dims& dd = *s->d_dec;
+  hipStream_t st = (hipStream_t)stream;
+  hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
+  Events& ev = g_events;
+  const StepWs w = step_ws(dd, s->ws_step);
+  const long long nz = (long long)dd.B * dd.Z;
+  // packed gradient buffers start at zero; the decoder's weights are packed on the side stream, they are
+  // not needed before the encoder is through
+  DVAE_TRY(k_zero(s->Ge, dvae_enc_grad_floats(&de) * sizeof(float), st));
+  DVAE_TRY(k_zero(s->Gd, dvae_dec_grad_floats(&dd) * sizeof(float), st));
+  DVAE_TRY(dvae_pack_params(s->enc_table, s->enc_n, s->Pe, st));
+  DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(dvae_pack_params(s->dec_table, s->dec_n, s->Pd, sd));
+  DVAE_TRY(dvae_encoder_fwd(&de, s->x, s->sizes, s->sched, s->info_host, s->Pe, s->ws_enc, nullptr, w.mu, w.logvar,
+                            nullptr, nullptr, st));
+  DVAE_TRY(dvae_reparam_fwd(w.mu, w.logvar, s->eps, w.z, nz, st));
+  DVAE_TRY(ev.edge(sd, st));
+  DVAE_TRY(dvae_decoder_fwd(&dd, w.z, s->x, s->sizes, s->sched, s->info_host, s->Pd, s->ws_dec, w.edge_logits,
+                            w.type_logits, nullptr, st, side_stream));
+  DVAE_TRY(dvae_elbo(&dd, w.edge_logits, w.type_logits, s->g, s->x, s->sizes, w.mu, w.logvar, s->beta, s->out4,
+                     w.elbo_part, w.d_edge, w.d_type, w.d_mu, w.d_logvar, st));
+  DVAE_TRY(dvae_decoder_bwd(&dd, w.z, s->x, s->sizes, s->sched, s->info_host, s->Pd, s->ws_dec, w.d_edge, w.d_type,
+                            s->Gd, w.d_z, st, side_stream));
+  DVAE_TRY(dvae_reparam_bwd(w.d_z, w.logvar, s->eps, w.dmu2, w.dlv2, nz, st));
+  DVAE_TRY(k_add_rows(w.d_mu, dd.Z, w.dmu2, dd.Z, dd.B, dd.Z, st));
+  DVAE_TRY(k_add_rows(w.d_logvar, dd.Z, w.dlv2, dd.Z, dd.B, dd.Z, st));
+  return DVAE_OK;
+}
+
+extern "C" int dvae_step_part2(const dvae_step* s, void* stream, void* side_stream) {
+  DVAE_REQUIRE(s && s->d_enc && s->d_dec && s->x && s->sched && s->info_host && s->Pe && s->ws_enc && s->ws_step && s->Ge,
+               "step_part2: null pointer");
+  const StepWs w = step_ws(*s->d_dec, s->ws_step);
+  return dvae_encoder_bwd(s->d_enc, s->x, s->sizes, s->sched, s->info_host, s->Pe, s->ws_enc, nullptr, w.d_mu,
+                          w.d_logvar, s->Ge, stream, side_stream);
+}

@@ -244,7 +244,8 @@ class ParamPack:
         self.gfloats = int(f_gfloats(ctypes.byref(dims)))
         self.P = torch.zeros(self.nfloats, dtype=torch.float32, device=dev)
 
-    def pack(self, dims, params):
+    def ensure(self, dims, params):
+        """Table and packed buffer for these parameters (rebuilt when a storage or a shape changed)."""
         shape = tuple(getattr(dims, f) for f, _ in dims._fields_ if f not in ("B", "T"))   # batch-independent fields
         key = shape + tuple(p.data_ptr() for p in params)
         if key != self.key:
@@ -253,6 +254,10 @@ class ParamPack:
                 assert p.dtype == torch.float32 and p.is_contiguous(), "parameters must be contiguous fp32"
             self._build(dims, params)
             self.key = key
+        return self.P
+
+    def pack(self, dims, params):
+        self.ensure(dims, params)
         check(load().dvae_pack_params(_ptr(self.table), self.n, _ptr(self.P), _stream()))
         return self.P
 
@@ -326,6 +331,33 @@ class DecoderCall:
                                       s.info_ptr, _ptr(self.P), _ptr(self.ws), _ptr(d_edge), _ptr(d_type), _ptr(G),
                                       _ptr(d_z), _stream(), _side(side)))
         return d_z
+
+
+class StepState:
+    """Persistent device buffers of the fused train step (dvae_step_part1 / part2): nothing is allocated
+    per step once the batch shape has been seen (workspaces grow to the largest schedule met)."""
+
+    def __init__(self, d_enc, d_dec, device):
+        lib = load()
+        self.d_enc, self.d_dec, self.device = d_enc, d_dec, device
+        self.ws_step = _workspace(lib.dvae_step_ws_bytes(ctypes.byref(d_dec)), device)
+        self.Ge = torch.empty(lib.dvae_enc_grad_floats(ctypes.byref(d_enc)), device=device)
+        self.Gd = torch.empty(lib.dvae_dec_grad_floats(ctypes.byref(d_dec)), device=device)
+        self.ws_enc = self.ws_dec = None
+        self.step = _lib.DvaeStep()
+        self.step.d_enc, self.step.d_dec = ctypes.pointer(d_enc), ctypes.pointer(d_dec)
+
+    def workspaces(self, R, E):
+        lib = load()
+        ne = lib.dvae_enc_ws_bytes(ctypes.byref(self.d_enc), R, E)
+        nd = lib.dvae_dec_ws_bytes(ctypes.byref(self.d_dec), R, E)
+        if self.ws_enc is None or self.ws_enc.numel() < ne:
+            self.ws_enc = _workspace(int(ne * 1.1) + 256, self.device)
+        if self.ws_dec is None or self.ws_dec.numel() < nd:
+            self.ws_dec = _workspace(int(nd * 1.1) + 256, self.device)
+        if _POISON:
+            self.ws_enc.fill_(255); self.ws_dec.fill_(255); self.ws_step.fill_(255)
+        return self.ws_enc, self.ws_dec
 
 
 def elbo_call(dims, edge_logits, type_logits, g, x, sizes, mu, logvar, beta, want_grads):

@@ -6,6 +6,8 @@ names (including the ``reparamterize`` spelling, :410), return values and
 The torch layers below only own the parameters (so checkpoints keep the
 reference's key names); no torch op touches the hot path.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -339,6 +341,14 @@ class Dvae(nn.Module):
             self._flat = (key, fe, fd, ve, vd)
         return self._flat[1:]
 
+    def _step_state(self, B, N, device):
+        key = (int(B), int(N), str(device))
+        if getattr(self, '_step', None) is None or self._step[0] != key:
+            d_enc = E._dims_for(self.encoder._dims, B, N)
+            d_dec = E._dims_for(self.decoder._dims, B, N)
+            self._step = (key, E.StepState(d_enc, d_dec, device))
+        return self._step[1]
+
     def prepare(self, batch, resident=False, on_side_stream=False):
         """Queue the level-schedule build of a FUTURE batch on a stream of its own and
         return at once; pass the result to ``loss_and_grad(batch, sched=...)``.  A data
@@ -385,32 +395,35 @@ class Dvae(nn.Module):
             else:
                 sched = self._schedule(batch)
             xs = E._f32c(x)
-            d_enc = E._dims_for(enc._dims, sched.B, sched.N)
-            d_dec = E._dims_for(dec._dims, sched.B, sched.N)
-            Pe = enc._pack.pack(d_enc, enc_p)
             fe, fd, ve, vd = self._flat_grads()
             side = E.side_stream(main.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):     # the decoder's weights are not needed before the encoder is through
-                Pd = dec._pack.pack(d_dec, dec_p)
-                pd_ready = torch.cuda.Event()
-                pd_ready.record(side)
-            handles = []
-            ec = E.EncoderCall(d_enc, sched, xs, Pe)
+            st = self._step_state(sched.B, sched.N, main.device)
+            enc._pack.ensure(st.d_enc, enc_p)
+            dec._pack.ensure(st.d_dec, dec_p)
             if eps is None:
-                eps = torch.randn_like(ec.mu)
-            z = E.reparam_fwd(ec.mu, ec.logvar, eps)
-            main.wait_event(pd_ready)
-            dc = E.DecoderCall(d_dec, sched, z, xs, Pd, side=side)
-            out4, (ge, gt, gmu, glv) = E.elbo_call(d_dec, dc.edge_logits, dc.type_logits, sched.g, xs, sched.sizes,
-                                                   ec.mu, ec.logvar, float(beta), True)
-            Gd = dec._pack.new_packed_grad()
-            Ge = enc._pack.new_packed_grad()
-            # the weight-gradient products run on `side` beside the per-level chains; the
-            # decoder's unpack + all-reduce are queued there too, under the encoder's backward
-            d_z = dc.backward(ge, gt, Gd, side=side)
+                eps = torch.randn(sched.B, enc.latent_space_dim, device=main.device)
+            eps = E._f32c(eps)
+            assert eps.shape == (sched.B, enc.latent_space_dim), "eps must be [B,%d]" % enc.latent_space_dim
+            out4 = E._out(4, device=main.device)
+            ws_enc, ws_dec = st.workspaces(sched.R, sched.E)
+            c = st.step
+            c.g, c.x = sched.g.data_ptr(), xs.data_ptr()
+            c.sizes = None if sched.sizes is None else sched.sizes.data_ptr()
+            c.sched, c.info_host = sched.buf.data_ptr(), sched.info.ctypes.data
+            c.enc_table, c.enc_n = enc._pack.table.data_ptr(), enc._pack.n
+            c.dec_table, c.dec_n = dec._pack.table.data_ptr(), dec._pack.n
+            c.Pe, c.Pd = enc._pack.P.data_ptr(), dec._pack.P.data_ptr()
+            c.ws_enc, c.ws_dec, c.ws_step = ws_enc.data_ptr(), ws_dec.data_ptr(), st.ws_step.data_ptr()
+            c.eps, c.beta = eps.data_ptr(), float(beta)
+            c.Ge, c.Gd, c.out4 = st.Ge.data_ptr(), st.Gd.data_ptr(), out4.data_ptr()
+            handles = []
+            raw_main, raw_side = E._stream(), E._side(side)
+            side.wait_stream(main)
+            # part 1: everything up to the decoder's backward (its weight-gradient products and the
+            # decoder's unpack + all-reduce run on `side`, under the encoder's backward)
+            E.check(E.load().dvae_step_part1(ctypes.byref(c), raw_main, raw_side))
             with torch.cuda.stream(side):
-                dec._pack.unpack(Gd, fd)
+                dec._pack.unpack(st.Gd, fd)
                 h = grad_sync(fd) if grad_sync is not None else None
                 if on_decoder_grads is not None and not self._shared_gm:
                     if h is not None:
@@ -420,15 +433,13 @@ class Dvae(nn.Module):
                     on_decoder_grads()
                 elif h is not None:
                     handles.append(h)
-            dmu, dlv = E.reparam_bwd(d_z, ec.logvar, eps)
-            gmu.add_(dmu)
-            glv.add_(dlv)
-            ec.backward(None, gmu, glv, Ge, side=side)
+            E.check(E.load().dvae_step_part2(ctypes.byref(c), raw_main, raw_side))
             with torch.cuda.stream(side):
-                enc._pack.unpack(Ge, fe)
+                enc._pack.unpack(st.Ge, fe)
                 if grad_sync is not None:
                     handles.append(grad_sync(fe))
             main.wait_stream(side)
+            self._step_keep = (sched, xs, eps)       # inputs of the queued kernels stay alive until the next step
             for h in handles:
                 if h is not None:
                     h.wait()

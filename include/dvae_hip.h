@@ -220,6 +220,35 @@ int dvae_decoder_bwd(const dvae_dims* d, const float* z, const float* x, const i
                      const float* d_edge_logits, const float* d_type_logits, float* G, float* d_z,
                      void* stream, void* side_stream);
 
+/* ------------------------------------------------------------------------
+ * One fused train step in two calls: Dvae.forward + training_step's loss (dvae_model.py:415-432) and
+ * the backward that Lightning runs after it, without a host language in between.  Same kernels in
+ * the same order as the entry points above (results are bit-identical to calling them one by one);
+ * this only removes the per-call host work, which is what a small batch is bound by.
+ *   part 1: zero Ge/Gd, pack both parameter sets (the decoder's on the side stream), encoder fwd,
+ *           reparameterise with the injected eps, decoder fwd, ELBO + gradients, decoder bwd,
+ *           reparameterise bwd.  On return Gd is complete once the SIDE stream has drained.
+ *   part 2: encoder bwd.  On return Ge is complete once the side stream has drained.
+ * The caller unpacks / all-reduces Gd between the two calls (on the side stream), Ge after part 2.
+ * ws_step: dvae_step_ws_bytes(d_dec) bytes (mu, logvar, z, logits and their gradients, ELBO partials);
+ * ws_enc / ws_dec: as for dvae_encoder_fwd / dvae_decoder_fwd; all kept until part 2 has run.
+ * ---------------------------------------------------------------------- */
+typedef struct dvae_step {
+  const dvae_dims* d_enc; const dvae_dims* d_dec;     /* same B, N, C, H, Z; bidir only in d_enc           */
+  const float* g; const float* x; const int* sizes;   /* the batch (sizes may be NULL)                      */
+  const void* sched; const int* info_host;            /* dvae_sched_build (+ dvae_sched_types) results      */
+  const dvae_pack_entry* enc_table; int enc_n;        /* DEVICE pack tables                                 */
+  const dvae_pack_entry* dec_table; int dec_n;
+  float* Pe; float* Pd;                               /* packed parameter buffers (written by part 1)       */
+  void* ws_enc; void* ws_dec; void* ws_step;
+  const float* eps; float beta;                       /* eps [B][Z]; loss = edge + vertex + beta * kl       */
+  float* Ge; float* Gd;                               /* packed gradient buffers (zeroed by part 1)         */
+  float* out4;                                        /* {edge_loss, vertex_loss, kl_loss, loss}            */
+} dvae_step;
+size_t dvae_step_ws_bytes(const dvae_dims* d);
+int dvae_step_part1(const dvae_step* s, void* stream, void* side_stream);
+int dvae_step_part2(const dvae_step* s, void* stream, void* side_stream);
+
 /* Tuning / test knob of the forward level sweep (no counterpart in the reference): node rows
  * per level from which the gate/map step runs as ONE fused launch (GEMM + sigmoid*map
  * epilogue; -1 never, 0 always, default 2048) and whether the GRU step runs fused (hidden
