@@ -120,3 +120,66 @@ def test_sharded_map_gathers_in_row_order():
         mp.spawn(_map_worker, args=(world, port, ret), nprocs=world, join=True)
         assert ret[0] == (4, True, True, True), ret[0]
         assert ret[1] == (3, True, True, True), ret[1]
+
+
+class _StubModel(torch.nn.Module):
+    """Lightning-style hooks over a 1-parameter model: loss = w^2 * (graphs in the shard) / 2."""
+
+    def __init__(self, w0, data):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor([float(w0)]))
+        self.data = data
+        self.seen = []
+
+    def training_step(self, batch, i):
+        self.seen.append(int(batch['graph'].shape[0]))
+        loss = (self.w ** 2).sum() * batch['graph'].shape[0] / 2
+        v = float(loss)
+        return {'loss': loss, 'log': {'train/edge_loss': v, 'train/vertex_loss': 0.0, 'train/kl_loss': 0.0, 'train/loss': v}}
+
+    def configure_optimizers(self):
+        opt = torch.optim.SGD(self.parameters(), lr=0.01)
+        return [opt], [torch.optim.lr_scheduler.ReduceLROnPlateau(opt)]
+
+    def train_dataloader(self):
+        return self.data
+
+    def val_dataloader(self):
+        return None
+
+
+def _trainer_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dvae_amd import trainer
+    torch.manual_seed(100 + rank)          # ranks start with DIFFERENT generator states and weights
+    # 5 graphs, 4 graphs, then a tail batch of ONE graph: fewer graphs than ranks
+    data = [{'graph': torch.ones(5, 2, 2)}, {'graph': torch.ones(4, 2, 2)}, {'graph': torch.ones(1, 2, 2)}]
+    m = _StubModel(3.0 + rank, data)
+    t = trainer.Trainer(max_epochs=1, dist=dist, fused=False, log=lambda r: None)
+    hist = t.fit(m)
+    ret[rank] = (float(m.w), list(m.seen), hist[0]['steps'], torch.initial_seed() if False else int(torch.randint(0, 1 << 30, (1,))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_data_parallel_broadcast_seed_and_tail_batch():
+    """Trainer under data parallelism: rank 0's weights are broadcast, the shuffle seed is shared (ranks
+    draw the same numbers afterwards), every rank takes its shard of each batch, and a tail batch with fewer
+    graphs than ranks is dropped by ALL ranks instead of leaving one of them out of the all-reduce."""
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_trainer_worker, args=(world, port, ret), nprocs=world, join=True)
+        (w0, seen0, steps0, r0), (w1, seen1, steps1, r1) = ret[0], ret[1]
+        assert steps0 == steps1 == 2                        # the 1-graph tail batch was dropped everywhere
+        assert seen0 == [3, 2] and seen1 == [2, 2]          # contiguous shards of 5 and 4 graphs
+        assert r0 == r1                                     # same generator state after the shared epoch seed
+        # both started from rank 0's w = 3 and applied the SUM-reduced gradient: w <- w - lr * w * (graphs in batch)
+        want = 3.0
+        for n in (5, 4):
+            want -= 0.01 * want * n
+        assert abs(w0 - want) < 1e-6 and abs(w1 - want) < 1e-6, (w0, w1, want)
