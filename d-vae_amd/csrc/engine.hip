@@ -24,7 +24,9 @@ struct LevelCfg {
   LevelCfg() {
     type_share = getenv("DVAE_NO_TYPE_SHARE") ? 0 : 1;
     fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : getenv("DVAE_FUSED_GM_MIN") ? atoi(getenv("DVAE_FUSED_GM_MIN")) : 2048;
-    fused_gru = (!getenv("DVAE_UNFUSED") && getenv("DVAE_FUSED_GRU")) ? 1 : 0;
+    // 0: hidden GEMM + gate kernel; 1: fused hidden GEMM + gates; 2: node sweeps run aggregation + hidden GEMM +
+    // gates as ONE launch (level.hip GATHER kernels), everything else as 0
+    fused_gru = (!getenv("DVAE_UNFUSED") && getenv("DVAE_FUSED_GRU")) ? std::max(1, atoi(getenv("DVAE_FUSED_GRU"))) : 0;
   }
 };
 LevelCfg g_level_cfg;
@@ -285,7 +287,7 @@ bool skip_level0(const int* info) { return scored_rows_only() && info[7] == 1; }
 
 // prefix sweeps in mod None sum the GRU's hidden product from one product per node (kernels.h SweepBufs::PG)
 bool node_hidden(const dvae_dims& d, const SweepBufs& b) {
-  return g_level_cfg.node_hidden && b.prefix && d.mod == 0 && !g_level_cfg.fused_gru;
+  return g_level_cfg.node_hidden && b.prefix && d.mod == 0 && g_level_cfg.fused_gru != 1;
 }
 
 struct SweepW {
@@ -312,7 +314,8 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   // than "64x128-tile GEMM + gru_fwd_kernel" on MI355X (a workgroup must hold all three
   // gates of its hidden units, which leaves 2 instead of 3 waves per SIMD): opt-in through
   // dvae_level_tune / DVAE_FUSED_GRU=1.
-  const bool fused_gru = g_level_cfg.fused_gru != 0;
+  const bool fused_gru = g_level_cfg.fused_gru == 1;
+  const bool gather_gru = g_level_cfg.fused_gru == 2 && !b.prefix && d.mod == 0;
   const int fused_gm_min = g_level_cfg.fused_gm_min_rows;
   static const bool fold_partials = getenv("DVAE_NO_FOLD") == nullptr;   // A-B tests: combine launch instead
   auto gru_rows = [&](int p0, int p1) -> int {
@@ -347,8 +350,15 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
     int p0 = ns, p1 = ne;
     static const bool split_pg = getenv("DVAE_PG_SPLIT") != nullptr;   // lab: aggregation and gates as two launches
-    if (!(pg && L > 0 && !split_pg)) DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st, pg ? 1 : 0));
-    if (L == 0) {
+    if (gather_gru && L > 0) {
+      // aggregation + hidden GEMM + GRU gates of this level's node rows in one launch
+      DVAE_TRY(k_level_agg_gru_fwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, g.prio, st));
+    } else if (!(pg && L > 0 && !split_pg)) {
+      DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st, pg ? 1 : 0));
+    }
+    if (gather_gru && L > 0) {
+      // (done above)
+    } else if (L == 0) {
       if (h0) DVAE_TRY(gru_rows(ns, ne));
       else DVAE_TRY(k_gru_fwd(S, ns, ne, 1, b, x, d.N, d.C, w.gru, HP, st));
     } else {

@@ -70,6 +70,9 @@ int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const
                     const GruW& w, int HP, int prio, hipStream_t st);
 int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
                    int HP, int prio, hipStream_t st);
+// node sweeps, levels >= 1: CSR gated-sum aggregation (in the A-tile loader) + hidden GEMM + GRU gates, one launch
+int k_level_agg_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
+                        const GruW& w, int HP, int prio, hipStream_t st);
 // with_gm_grad=0 (mod bn): only gathers dGM into GMP[:, :HP] scaled for the weight grads
 int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 // parts: the gate/map input gradient of node rows [parts_row0, ..) as split-K slabs (GemmDesc::partials),

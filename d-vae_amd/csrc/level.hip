@@ -44,6 +44,10 @@ struct LevelCore {
   int K, HP;
   int tiles_n, nblk;
   int prio;
+  // GATHER kernels: the A rows do not exist yet -- row m is the gated sum over the predecessors of node row
+  // r_base + m (dvae_model.py:77-80), summed by the tile loader from GM through the CSR lists
+  const float* GM; const int* csr_ptr; const int* csr_idx; int r_base;
+  float* AGG;                       // the summed rows are also written here (the backward pass reads them)
 };
 
 struct GruEpi {
@@ -64,7 +68,10 @@ struct GmEpi {
 struct GruRow { int p, r; const float* xr; int hot; float xv; bool fin; };
 
 // row m of the launch, hidden units [col, col+4): v[g] = the G pre-activations
-__device__ __forceinline__ void epilogue(const GruEpi& e, int HP, const GruRow& rw, int col, const float4* v) {
+// gather (GATHER kernels): h_in is summed again from GM here -- the AGG row is being written by another
+// workgroup (the first column tile) and may not be complete yet
+__device__ __forceinline__ void epilogue(const GruEpi& e, int HP, const GruRow& rw, int col, const float4* v,
+                                         const LevelCore* gather = nullptr) {
   float4 gi[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) gi[g] = ld4(e.w.bih + g * HP + col);
@@ -83,7 +90,14 @@ __device__ __forceinline__ void epilogue(const GruEpi& e, int HP, const GruRow& 
   const float4 ghr = add4(ld4(e.w.bhh + col), v[0]);
   const float4 ghz = add4(ld4(e.w.bhh + HP + col), v[1]);
   const float4 ghn = add4(ld4(e.w.bhh + 2 * HP + col), v[2]);
-  const float4 a = ld4(e.AGG + (size_t)rw.p * HP + col);
+  float4 a;
+  if (gather) {
+    const int c0 = gather->csr_ptr[rw.p], c1 = gather->csr_ptr[rw.p + 1];
+    a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = c0; c < c1; ++c) a = add4(a, ld4(gather->GM + (size_t)gather->csr_idx[c] * HP + col));
+  } else {
+    a = ld4(e.AGG + (size_t)rw.p * HP + col);
+  }
   float4 rr, zz, nn, hh;
 #define GRU_LANE(f)                                   \
   rr.f = sigm(gi[0].f + ghr.f);                       \
@@ -103,7 +117,8 @@ __device__ __forceinline__ void epilogue(const GruEpi& e, int HP, const GruRow& 
 
 struct GmRow { int r; const float* pb; };
 
-__device__ __forceinline__ void epilogue(const GmEpi& e, int HP, const GmRow& rw, int col, const float4* v) {
+__device__ __forceinline__ void epilogue(const GmEpi& e, int HP, const GmRow& rw, int col, const float4* v,
+                                         const LevelCore* = nullptr) {
   const float4 gpre = add4(v[0], ld4(rw.pb + col));
   const float4 mm = add4(v[1], ld4(rw.pb + HP + col));
   const float4 g = make_float4(sigm(gpre.x), sigm(gpre.y), sigm(gpre.z), sigm(gpre.w));
@@ -134,9 +149,14 @@ __device__ __forceinline__ GmRow row_meta(const GmEpi& e, int HP, int m) {
   return rw;
 }
 
+// predecessors kept in registers per loader row; longer lists continue from the CSR array in memory
+constexpr int GATHER_REG = 8;
+
 // G gates, TM row sub-tiles per wave: workgroup tile = (64*TM) rows x (G x 64) columns,
 // four waves as 2 (rows) x 2 (hidden units), each wave TM x G MFMA tiles of 32x32.
-template <int G, int TM, class Epi>
+// GATHER: "gated-sum predecessor aggregation + GRUCell gate GEMM" in ONE launch: the A-tile loader sums the
+// predecessors' GM rows (CSR slice of the tile's rows held in registers) instead of reading a finished AGG row.
+template <int G, int TM, class Epi, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
   constexpr int BM = 64 * TM;
   constexpr int A_FLOATS = BM * LDM, B_FLOATS = G * BNG * LDM;
@@ -166,8 +186,22 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
   const int lr = tid / KQ, kq = (tid % KQ) * 4;
   const float* pa[NVA];
   const float* pb[NVB];
+  int gdeg[NVA], gc0[NVA], gidx[NVA][GATHER_REG];
+  (void)gdeg; (void)gc0; (void)gidx;
 #pragma unroll
-  for (int i = 0; i < NVA; ++i) pa[i] = p.A + (size_t)min(m0 + lr + RS * i, p.M - 1) * p.lda + kq;
+  for (int i = 0; i < NVA; ++i) {
+    const int m = min(m0 + lr + RS * i, p.M - 1);
+    pa[i] = (GATHER ? p.AGG + (size_t)(p.r_base + m) * p.HP : p.A + (size_t)m * p.lda) + kq;
+    if (GATHER) {
+      const int r = p.r_base + m;
+      gc0[i] = p.csr_ptr[r];
+      gdeg[i] = p.csr_ptr[r + 1] - gc0[i];
+#pragma unroll
+      for (int j = 0; j < GATHER_REG; ++j) gidx[i][j] = j < gdeg[i] ? p.csr_idx[gc0[i] + j] : 0;
+    }
+  }
+  // the first column tile of every row tile writes the summed rows out (rows beyond M are clamped copies)
+  const bool agg_out = GATHER && n0 == 0;
 #pragma unroll
   for (int i = 0; i < NVB; ++i) {
     const int row = lr + RS * i;   // LDS row = gate * 64 + hidden unit
@@ -176,7 +210,21 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
   float4 va[NVA], vb[NVB];
   auto load = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < NVA; ++i) va[i] = ld4(pa[i] + k0);
+    for (int i = 0; i < NVA; ++i) {
+      if (!GATHER) {
+        va[i] = ld4(pa[i] + k0);
+      } else {
+        // same order as agg_fwd_kernel (CSR order), so the sums carry the same bits
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < GATHER_REG; ++j)
+          if (j < gdeg[i]) acc = add4(acc, ld4(p.GM + (size_t)gidx[i][j] * p.HP + kq + k0));
+        for (int j = GATHER_REG; j < gdeg[i]; ++j)
+          acc = add4(acc, ld4(p.GM + (size_t)p.csr_idx[gc0[i] + j] * p.HP + kq + k0));
+        va[i] = acc;
+        if (agg_out) st4(const_cast<float*>(pa[i]) + k0, acc);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NVB; ++i) vb[i] = ld4(pb[i] + k0);
   };
@@ -236,22 +284,22 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
 #pragma unroll
       for (int g = 0; g < G; ++g)
         v[g] = make_float4(acc[i][g][4 * q], acc[i][g][4 * q + 1], acc[i][g][4 * q + 2], acc[i][g][4 * q + 3]);
-      epilogue(e, p.HP, rw, col, v);
+      epilogue(e, p.HP, rw, col, v, GATHER ? &p : nullptr);
     }
   }
 }
 
-template <int G, class Epi>
+template <int G, class Epi, bool GATHER = false>
 int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
   c.tiles_n = c.HP / BNG;
   const bool big = (long long)cdiv(c.M, 128) * c.tiles_n >= 512;
   void* pr = gemm_prof_begin(2.0 * c.M * G * c.HP * (double)c.K, st);
   if (big) {
     c.nblk = cdiv(c.M, 128) * c.tiles_n;
-    hipLaunchKernelGGL((level_kernel<G, 2, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+    hipLaunchKernelGGL((level_kernel<G, 2, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);
   } else {
     c.nblk = cdiv(c.M, 64) * c.tiles_n;
-    hipLaunchKernelGGL((level_kernel<G, 1, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+    hipLaunchKernelGGL((level_kernel<G, 1, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);
   }
   gemm_prof_end(pr, st);
   DVAE_LAUNCH_CHECK();
@@ -269,6 +317,21 @@ int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const
   c.W = w.Whh; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
   GruEpi e{S, b.R, b.prefix, p0, x, N, C, w, b.AGG, b.GH, b.GHN, b.HV, b.Hn};
   return launch_level<3>(c, e, st);
+}
+
+// node sweeps (encoder, both directions), levels >= 1: aggregation + hidden GEMM + GRU gates of node rows
+// [ns,ne) in ONE launch; also writes the AGG rows the backward pass needs
+int k_level_agg_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
+                        const GruW& w, int HP, int prio, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  DVAE_REQUIRE(HP % BNG == 0, "level_agg_gru: HP must be a multiple of 64");
+  DVAE_REQUIRE(!b.prefix, "level_agg_gru: node sweeps only");
+  LevelCore c{};
+  c.A = nullptr; c.lda = HP; c.M = ne - ns;
+  c.W = w.Whh; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
+  c.GM = b.GM; c.csr_ptr = S.csr_ptr; c.csr_idx = S.csr_idx; c.r_base = ns; c.AGG = b.AGG;
+  GruEpi e{S, b.R, 0, ns, x, N, C, w, b.AGG, b.GH, b.GHN, b.HV, b.Hn};
+  return launch_level<3, GruEpi, true>(c, e, st);
 }
 
 int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,

@@ -40,7 +40,8 @@ def test_fused_level_kernels(cuda, bidir):
         ref = _step(model, X, eps)
         with torch.no_grad():
             ref_states = model.encoder.node_states(X)[0].clone()
-        for gm_min, gru in ((0, 0), (0, 1), (-1, 1)):
+        # gru = 2: node sweeps run CSR aggregation + hidden GEMM + GRU gates as ONE launch (the gather loader)
+        for gm_min, gru in ((0, 0), (0, 1), (-1, 1), (-1, 2), (0, 2)):
             lib.dvae_level_tune(gm_min, gru, 1)
             out = _step(model, X, eps)
             with torch.no_grad():
