@@ -89,3 +89,38 @@ def get_dataloaders(batch_size, file_path, fmt=None, task_type='enas'):
     mk = lambda split, shuffle: DataLoader(NASDataset(file_path, split, fmt, task_type), batch_size=batch_size,
                                            pin_memory=True, shuffle=shuffle)
     return mk('train', True), (mk('val', False),), mk('test', False)
+
+
+class ScheduledLoader:
+    """Loader wrapper for the fused train step ("emit CSR + levels directly"): walks
+    `loader` ONE BATCH AHEAD, copies the next batch to the model's device and queues its level schedule --
+    levels, CSR / CSC lists, prefix rows, built on the device from the dense adjacency by
+    `Dvae.prepare` -- on a stream of its own, so that the schedule's host round trip is over by the
+    time the step needs it.  Yields `(batch_on_device, schedule)`; pass both to
+    `model.loss_and_grad(batch, sched=schedule)`.  The dense `[B,N,N]` batch format of the reference
+    (dataloader.py:104-108) is kept: at 256 bytes per 8-node graph the device-side build (~30 us per
+    batch) is cheaper than any host-side CSR."""
+
+    def __init__(self, loader, model, shard=None):
+        self.loader, self.model, self.shard = loader, model, shard
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch):
+        dev = next(self.model.parameters()).device
+        if self.shard is not None:
+            batch = self.shard(batch)
+        batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        return batch, self.model.prepare(batch)          # prepare() orders its stream after the copies
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        for raw in it:
+            cur, nxt = nxt, self._stage(raw)
+            yield cur
+        yield nxt

@@ -101,9 +101,28 @@ class Trainer:
                 seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64).to(dev)
                 self.dist.broadcast(seed, 0)
                 torch.manual_seed(int(seed.item()))     # the loader's RandomSampler seeds itself from this generator
-            for i, batch in enumerate(model.train_dataloader()):
+            loader = model.train_dataloader()
+            prepared = fused and hasattr(model, 'prepare')      # Dvae: level schedules built ahead of the step
+            if prepared:
+                # D-VAE fused path: batches staged and their level schedules built one batch ahead
+                from .data import ScheduledLoader
+
+                def stage(b):
+                    if world > 1 and next(v for v in b.values() if torch.is_tensor(v)).shape[0] < world:
+                        return None
+                    return dp.shard_batch(b, rank, world) if world > 1 else b
+                loader = ScheduledLoader((b for b in (stage(raw) for raw in loader) if b is not None), model)
+            for i, item in enumerate(loader):
                 if self.max_steps is not None and i >= self.max_steps:
                     break
+                if prepared:
+                    batch, sched = item
+                    out4 = model.loss_and_grad(batch, grad_sync=sync, sched=sched)
+                    opt.step()
+                    sums += dp.allreduce_losses(self.dist, out4.detach().clone()).double().cpu()
+                    steps += 1
+                    continue
+                batch = item
                 if world > 1 and next(v for v in batch.values() if torch.is_tensor(v)).shape[0] < world:
                     continue    # a tail batch with fewer graphs than ranks would leave a rank without work (the
                                 # reference's loader has no drop_last, dataloader.py:118-126): all ranks drop it
