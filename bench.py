@@ -242,6 +242,7 @@ def main():
                     help="lab: the decoder's Adam as an instance of its own, stepped on the side stream as soon as its "
                          "gradients are final (under the encoder's backward); measured 0.07-0.1 ms SLOWER than one "
                          "fused Adam after the step at B = 512 ... 4096, so it is not the default")
+    ap.add_argument("--no-weak-probe", action="store_true", help="N > 1: skip the fixed-per-GPU-batch probe after the timed region")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: ranks rendezvous over gloo, rank 0 prints the line")
     args = ap.parse_args()
@@ -336,6 +337,7 @@ def main():
         on_side = dist is not None     # with RCCL in the process: no third stream, the side stream builds it
 
         def step(i):
+            nb = len(batches)
             sched = prepared.pop(i, None)
             if prefetch and on_side:   # queued ahead of this step's own side-stream work (idle until the decoder starts)
                 prepared[i + 1] = model.prepare(batches[(i + 1) % nb], resident=True, on_side_stream=True)
@@ -374,6 +376,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         rccl_ranks = dist.get_world_size()
+    # N > 1: the same step at a FIXED per-GPU batch (= the configuration's batch on every GPU) right after the
+    # timed region -- the weak-scaling point beside the strong-scaling `value` (the global batch of the metric
+    # leaves each of 8 GPUs a 512-graph shard, which is launch-bound; this shows what the exchange itself costs)
+    weak_probe = None
+    if cfg["kind"] == "train" and dist is not None and not weak and cfg["N"] <= 16 and not args.no_weak_probe:
+        wb, _ = make_batches(cfg, B_cfg * world, rank, world, dev, 2)
+        prepared.clear()
+        batches[:] = wb
+        nb = len(wb)
+        for i in range(2):
+            step(1000 + i)
+        barrier()
+        wsteps = max(4, min(10, args.steps))
+        tw = time.perf_counter()
+        for i in range(wsteps):
+            step(1002 + i)
+        barrier()
+        tw = torch.tensor([time.perf_counter() - tw], device=dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak_probe = {"per_gpu_batch": B_cfg, "global_batch": B_cfg * world, "steps": wsteps,
+                      "ms_per_step": float(tw) / wsteps * 1e3, "value": B_cfg * world * wsteps / float(tw),
+                      "unit": "DAGs/s", "scaling": "weak"}
     if cfg["kind"] == "train":
         final = float(out[3])
         assert math.isfinite(final), "loss is not finite"
@@ -400,6 +424,8 @@ def main():
                 res["config"]["depth"] = round(dvae_amd.synth.graph_stats(g0)[1], 2)
         if rccl_ranks is not None:
             res["rccl_ranks"] = rccl_ranks
+        if weak_probe is not None:
+            res["weak_scaling_probe"] = weak_probe
         if gemm is not None:
             # dominant kernel: gemm_f32_kernel (all three layouts are one template)
             launches = gemm[0] + gemm[3] + gemm[9]
