@@ -72,12 +72,15 @@ SIGNATURES = {
                               c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "dvae_gemm_f32_mapped": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dvae_small_gemm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_void_p]),
     "dvae_gemm_force_tile": (c_int, [c_int]),
     "dvae_gemm_tune": (c_int, [c_int, c_int]),
     "dvae_gemm_variant": (c_int, [c_int]),
     "dvae_gemm_force_splits": (c_int, [c_int]),
     "dvae_gemm_dbg": (c_int, [c_int]),
     "dvae_level_tune": (c_int, [c_int, c_int, c_int]),
+    "dvae_small_rows_tune": (c_int, [c_int]),
     "dvae_wgrad_split_tune": (c_int, [ctypes.c_double, c_int]),
     "dvae_gemm_profile": (c_int, [c_int]),
     "dvae_gemm_profile_read": (c_int, [c_void_p]),

@@ -21,6 +21,9 @@ namespace {
 struct LevelCfg {
   int fused_gm_min_rows; int fused_gru; int type_share;
   int node_hidden = getenv("DVAE_NO_NODE_HIDDEN") ? 0 : 1;   // prefix sweeps: one hidden product per node (SweepBufs::PG)
+  // per-level products of at most this many rows run as level.hip small_kernel launches (32-row tiles, K split
+  // over the waves of a workgroup, gates fused in the forward pass); 0 = never.  DVAE_SMALL_ROWS / dvae_small_rows_tune
+  int small_rows = getenv("DVAE_SMALL_ROWS") ? atoi(getenv("DVAE_SMALL_ROWS")) : 1024;
   LevelCfg() {
     type_share = getenv("DVAE_NO_TYPE_SHARE") ? 0 : 1;
     fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : getenv("DVAE_FUSED_GM_MIN") ? atoi(getenv("DVAE_FUSED_GM_MIN")) : 2048;
@@ -318,8 +321,10 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   const bool gather_gru = g_level_cfg.fused_gru == 2 && !b.prefix && d.mod == 0;
   const int fused_gm_min = g_level_cfg.fused_gm_min_rows;
   static const bool fold_partials = getenv("DVAE_NO_FOLD") == nullptr;   // A-B tests: combine launch instead
+  const int small_rows = g_level_cfg.small_rows;
   auto gru_rows = [&](int p0, int p1) -> int {
     if (fused_gru) return k_level_gru_fwd(S, p0, p1, b, x, d.N, d.C, w.gru, HP, g.prio, st);
+    if (p1 - p0 <= small_rows) return k_level_gru_fwd_small(S, p0, p1, b, x, d.N, d.C, w.gru, HP, g.prio, st);
     GemmPartials parts{nullptr, 1, 0};   // a small level's split-K slabs go to the gate kernel as they are
     DVAE_TRY(g.nt(b.AGG + (size_t)p0 * HP, HP, w.gru.Whh, HP, b.GH + (size_t)p0 * 3 * HP, 3 * HP, p1 - p0, 3 * HP, HP,
                   nullptr, 0, 0, nullptr, fold_partials ? &parts : nullptr));
@@ -371,6 +376,8 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     if (L + 1 < lv.nlev) {   // nodes of the last level have no successors
       if (fused_gm_min >= 0 && ne - ns >= fused_gm_min) {
         DVAE_TRY(k_level_gm_fwd(S, ns, ne, b, w.gm, w.gm + (size_t)2 * HP * HP, HP, g.prio, st));
+      } else if (ne - ns <= small_rows) {
+        DVAE_TRY(k_level_gm_fwd_small(S, ns, ne, b, w.gm, w.gm + (size_t)2 * HP * HP, HP, g.prio, st));
       } else {
         // a small level's product is split over K: its slabs go to the gate/map kernel as they are
         GemmPartials parts{nullptr, 1, 0};
@@ -379,7 +386,10 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
         DVAE_TRY(k_gm_fwd(S, ns, ne, b, w.gm + (size_t)2 * HP * HP, HP, st, &parts));
       }
       // the hidden product of this level's gated states, once per node
-      if (pg)
+      if (pg && ne - ns <= small_rows)
+        DVAE_TRY(k_small_gemm(b.GM + (size_t)ns * HP, HP, w.gru.Whh, HP, 0, b.PG + (size_t)ns * 3 * HP, 3 * HP, ne - ns, 3, HP,
+                              HP, 0, g.prio, st));
+      else if (pg)
         DVAE_TRY(g.nt(b.GM + (size_t)ns * HP, HP, w.gru.Whh, HP, b.PG + (size_t)ns * 3 * HP, 3 * HP, ne - ns, 3 * HP, HP));
     }
   }
@@ -394,7 +404,13 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   hipStream_t st = g.st;
   if (R <= 0) return DVAE_OK;
   const int z1 = lv.nlev > 0 ? lv.ls[1] : R;
+  const int small_rows = g_level_cfg.small_rows;
+  // dX[M][HP] += dY[M][K] . W[K][HP] on a small level: one launch, no split-K slabs
+  auto small_nn = [&](const float* dY, int K, const float* W, float* dX, int M) {
+    return k_small_gemm(dY, K, W, HP, 1, dX, HP, M, 1, HP, K, 1, g.prio, st);
+  };
   auto dagg_gemm = [&](int p0, int p1) {   // dAGG += dgh . Whh
+    if (p1 - p0 <= small_rows) return small_nn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, w.gru.Whh, b.DH + (size_t)p0 * HP, p1 - p0);
     return g.nn(b.GH + (size_t)p0 * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DH + (size_t)p0 * HP, HP, p1 - p0, HP, 3 * HP, 1);
   };
   if (d.mod == 1) {
@@ -424,15 +440,21 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
         // dL/dGM[u] = (direct gradients of the rows that hold u) + (their dgh, summed).Whh: the hidden
         // product's input gradient once per node instead of once per prefix row
         DVAE_TRY(k_dgm_gather(S, ns, ne, b, HP, st));
-        GemmPartials parts{nullptr, 1, 0};   // a small level's split-K slabs are added by the consumer
-        DVAE_TRY(g.nn(b.PG + (size_t)ns * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DGM + (size_t)ns * HP, HP, ne - ns, HP,
-                      3 * HP, 1, nullptr, fold_partials_bwd ? &parts : nullptr));
+        GemmPartials parts{nullptr, 1, 0};   // a mid-sized level's split-K slabs are added by the consumer
+        if (ne - ns <= small_rows)
+          DVAE_TRY(small_nn(b.PG + (size_t)ns * 3 * HP, 3 * HP, w.gru.Whh, b.DGM + (size_t)ns * HP, ne - ns));
+        else
+          DVAE_TRY(g.nn(b.PG + (size_t)ns * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DGM + (size_t)ns * HP, HP, ne - ns, HP,
+                        3 * HP, 1, nullptr, fold_partials_bwd ? &parts : nullptr));
         DVAE_TRY(k_gm_bwd_apply(ns, ne, b, HP, st, &parts));
       } else {
         DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
       }
-      DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
-                    2 * HP, 1, nullptr, fold_partials_bwd ? &gparts : nullptr));
+      if (ne - ns <= small_rows)
+        DVAE_TRY(small_nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, dtarget + (size_t)ns * HP, ne - ns));
+      else
+        DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
+                      2 * HP, 1, nullptr, fold_partials_bwd ? &gparts : nullptr));
     }
     if (L == 0) {
       DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st, &gparts, ns));
@@ -942,6 +964,12 @@ extern "C" int dvae_side_stream_destroy(void* stream) {
 extern "C" int dvae_wgrad_split_tune(double frac, int min_rows) {
   g_wgrad_split.frac = frac;
   g_wgrad_split.min_rows = min_rows;
+  return DVAE_OK;
+}
+
+// tuning / test knob: per-level products of at most `rows` rows take level.hip's small-level kernels (0 = never)
+extern "C" int dvae_small_rows_tune(int rows) {
+  g_level_cfg.small_rows = rows;
   return DVAE_OK;
 }
 

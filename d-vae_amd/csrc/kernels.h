@@ -70,6 +70,14 @@ int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const
                     const GruW& w, int HP, int prio, hipStream_t st);
 int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
                    int HP, int prio, hipStream_t st);
+// the same two fused steps and plain products for SMALL row counts (level.hip small_kernel: 32-row tiles, the
+// reduction split over the four waves of a workgroup)
+int k_level_gru_fwd_small(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+                          const GruW& w, int HP, int prio, hipStream_t st);
+int k_level_gm_fwd_small(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
+                         int HP, int prio, hipStream_t st);
+int k_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int G, int HP,
+                 int K, int accumulate, int prio, hipStream_t st);
 // node sweeps, levels >= 1: CSR gated-sum aggregation (in the A-tile loader) + hidden GEMM + GRU gates, one launch
 int k_level_agg_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
                         const GruW& w, int HP, int prio, hipStream_t st);

@@ -289,6 +289,162 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Small levels (<= ~1024 rows: the per-GPU shard of a strong-scaled batch, config 1, the thin deep levels of
+// large graphs).  There a 64-row tile grid leaves most CUs empty and every workgroup walks the whole reduction
+// alone (one 64x64x512 tile is 6.8 us of MFMA issue on its CU; splitting K over workgroups costs slabs and a
+// combine).  This kernel takes a 32-row x (G x 32-column) output tile per workgroup -- 256 workgroups for
+// 512 rows x 512 units -- and splits K over its FOUR WAVES: wave w stages and multiplies the k-tiles
+// w, w+4, .. on its own (wave-private LDS staging, no workgroup barrier in the k loop, so the waves drift apart
+// and hide each other's load latency), then the four partial accumulators meet in LDS in a fixed order
+// (deterministic) and wave q finishes register group q of every gate: the same per-lane layout as
+// level_kernel's epilogue, so the GRU / gate-map epilogues are shared.  BKM = 1: the weight operand is
+// k-major ([K][N], the backward products dX = dY . W).
+// ---------------------------------------------------------------------------
+constexpr int SBK = 16;            // k-tile of one wave
+constexpr int SLD = SBK + 4;       // row stride of an m-major staging tile
+constexpr int SKN = 40;            // row stride of a k-major staging tile ([k][32 n] padded: half-waves on disjoint banks)
+
+struct PlainEpi {   // C[row][g*HP + col] (+)= v[g] (+ bias)
+  float* C; int ldc; int accumulate; const float* bias;
+};
+struct PlainRow { int r; };
+__device__ __forceinline__ PlainRow row_meta(const PlainEpi&, int, int m) { return PlainRow{m}; }
+template <int G>
+__device__ __forceinline__ void epilogue_plain(const PlainEpi& e, int HP, const PlainRow& rw, int col, const float4* v) {
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float* dst = e.C + (size_t)rw.r * e.ldc + g * HP + col;
+    float4 x = v[g];
+    if (e.bias) x = add4(x, ld4(e.bias + g * HP + col));
+    if (e.accumulate) x = add4(x, ld4(dst));
+    st4(dst, x);
+  }
+}
+
+template <int G> __device__ __forceinline__ void small_epilogue(const GruEpi& e, int HP, const GruRow& rw, int col, const float4* v) { epilogue(e, HP, rw, col, v); }
+template <int G> __device__ __forceinline__ void small_epilogue(const GmEpi& e, int HP, const GmRow& rw, int col, const float4* v) { epilogue(e, HP, rw, col, v); }
+template <int G> __device__ __forceinline__ void small_epilogue(const PlainEpi& e, int HP, const PlainRow& rw, int col, const float4* v) { epilogue_plain<G>(e, HP, rw, col, v); }
+
+template <int G, class Epi, int BKM>
+__global__ __launch_bounds__(256) void small_kernel(LevelCore p, Epi e) {
+  constexpr int A_FL = 32 * SLD;
+  constexpr int B_FL = BKM ? G * SBK * SKN : G * 32 * SLD;
+  constexpr int STAGE = A_FL + B_FL;                 // per wave
+  constexpr int RED = G * 16 * 64;                   // per wave
+  constexpr int LDS_FL = (4 * STAGE > 4 * RED) ? 4 * STAGE : 4 * RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FL];
+  if (p.prio) __builtin_amdgcn_s_setprio(2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / p.tiles_n) * 32;
+  const int n0 = (tile % p.tiles_n) * 32;
+  float* As = lds + wave * STAGE;
+  float* Bs = As + A_FL;
+
+  f32x16 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+  // this lane's share of a k-tile: A 32 x 16 floats = 2 float4, B G x (32 x 16) floats = 2G float4
+  const float* pa[2];
+  const float* pb[2 * G];
+  int sa[2], sb[2 * G];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = lane + 64 * i, row = idx >> 2, kq = (idx & 3) * 4;
+    pa[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kq;
+    sa[i] = row * SLD + kq;
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * G; ++i) {
+    const int idx = lane + 64 * i;
+    if (BKM == 0) {
+      const int row = idx >> 2, kq = (idx & 3) * 4;          // row = gate * 32 + unit
+      pb[i] = p.W + ((size_t)(row >> 5) * p.HP + n0 + (row & 31)) * p.ldw + kq;
+      sb[i] = row * SLD + kq;
+    } else {
+      const int g = idx >> 7, kr = (idx & 127) >> 3, nq = (idx & 7) * 4;   // per gate: 16 k-rows x 8 float4
+      pb[i] = p.W + (size_t)kr * p.ldw + g * p.HP + n0 + nq;
+      sb[i] = g * SBK * SKN + kr * SKN + nq;
+    }
+  }
+  const int ntiles = p.K / SBK;
+  float4 va[2], vb[2 * G];
+  auto load = [&](int t) {
+    const size_t ka = (size_t)t * SBK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) va[i] = ld4(pa[i] + ka);
+#pragma unroll
+    for (int i = 0; i < 2 * G; ++i) vb[i] = ld4(pb[i] + (BKM ? ka * p.ldw : ka));
+  };
+  int t = wave;
+  if (t < ntiles) load(t);
+  for (; t < ntiles; t += 4) {
+    // registers -> this wave's staging tiles (the previous tile's fragments are consumed: same wave, in order)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st4(As + sa[i], va[i]);
+#pragma unroll
+    for (int i = 0; i < 2 * G; ++i) st4(Bs + sb[i], vb[i]);
+    if (t + 4 < ntiles) load(t + 4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kc = 0; kc < SBK / 8; ++kc) {
+      const float4 af = ld4(As + (lane & 31) * SLD + kc * 8 + (lane >> 5) * 4);
+      float4 bf[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (BKM == 0) {
+          bf[g] = ld4(Bs + (g * 32 + (lane & 31)) * SLD + kc * 8 + (lane >> 5) * 4);
+        } else {
+          const float* q = Bs + g * SBK * SKN + (kc * 8 + (lane >> 5) * 4) * SKN + (lane & 31);
+          bf[g] = make_float4(q[0], q[SKN], q[2 * SKN], q[3 * SKN]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].x, af.x, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].y, af.y, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].z, af.z, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[g].w, af.w, acc[g], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the four partial accumulators meet in LDS (over the staging area): red[wave][reg][lane]
+  __syncthreads();
+  float* red = lds;
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * G * 16 + g * 16 + r) * 64 + lane] = acc[g][r];
+  __syncthreads();
+  // wave q finishes register group q of every gate: row m0 + (lane & 31), columns n0 + 8q + 4*(lane>>5) + 0..3
+  const int q = wave;
+  const int m = m0 + (lane & 31);
+  if (m >= p.M) return;
+  float4 v[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float s[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r = g * 16 + 4 * q + c;
+      s[c] = ((red[(0 * G * 16 + r) * 64 + lane] + red[(1 * G * 16 + r) * 64 + lane]) +
+              red[(2 * G * 16 + r) * 64 + lane]) + red[(3 * G * 16 + r) * 64 + lane];
+    }
+    v[g] = make_float4(s[0], s[1], s[2], s[3]);
+  }
+  const auto rw = row_meta(e, p.HP, m);
+  const int col = n0 + 8 * q + 4 * (lane >> 5);
+  small_epilogue<G>(e, p.HP, rw, col, v);
+}
+
 template <int G, class Epi, bool GATHER = false>
 int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
   c.tiles_n = c.HP / BNG;
@@ -306,7 +462,55 @@ int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
   return DVAE_OK;
 }
 
+template <int G, class Epi, int BKM>
+int launch_small(LevelCore c, const Epi& e, hipStream_t st) {
+  c.tiles_n = c.HP / 32;
+  c.nblk = cdiv(c.M, 32) * c.tiles_n;
+  void* pr = gemm_prof_begin(2.0 * c.M * G * c.HP * (double)c.K, st);
+  hipLaunchKernelGGL((small_kernel<G, Epi, BKM>), dim3(c.nblk), dim3(256), 0, st, c, e);
+  gemm_prof_end(pr, st);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
 }  // namespace
+
+// plain products on small row counts: C[M][G*HP] (+)= A[M][K] . W^T, W = [G*HP][K] (w_kmajor = 0) or
+// C[M][HP] (+)= A[M][K] . W, W = [K][HP] (w_kmajor = 1, G = 1)
+int k_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int G, int HP,
+                 int K, int accumulate, int prio, hipStream_t st) {
+  if (M <= 0) return DVAE_OK;
+  DVAE_REQUIRE(HP % 32 == 0 && K % SBK == 0 && G >= 1 && G <= 3 && (!w_kmajor || G == 1), "small_gemm: unsupported shape");
+  LevelCore c{};
+  c.A = A; c.lda = lda; c.M = M; c.W = W; c.ldw = ldw; c.K = K; c.HP = HP; c.prio = prio;
+  PlainEpi e{C, ldc, accumulate, nullptr};
+  if (w_kmajor) return launch_small<1, PlainEpi, 1>(c, e, st);
+  if (G == 1) return launch_small<1, PlainEpi, 0>(c, e, st);
+  if (G == 2) return launch_small<2, PlainEpi, 0>(c, e, st);
+  return launch_small<3, PlainEpi, 0>(c, e, st);
+}
+
+int k_level_gru_fwd_small(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
+                          const GruW& w, int HP, int prio, hipStream_t st) {
+  if (p1 <= p0) return DVAE_OK;
+  DVAE_REQUIRE(HP % 32 == 0, "level_gru_small: HP must be a multiple of 32");
+  LevelCore c{};
+  c.A = b.AGG + (size_t)p0 * HP; c.lda = HP; c.M = p1 - p0;
+  c.W = w.Whh; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
+  GruEpi e{S, b.R, b.prefix, p0, x, N, C, w, b.AGG, b.GH, b.GHN, b.HV, b.Hn};
+  return launch_small<3, GruEpi, 0>(c, e, st);
+}
+
+int k_level_gm_fwd_small(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
+                         int HP, int prio, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  DVAE_REQUIRE(HP % 32 == 0, "level_gm_small: HP must be a multiple of 32");
+  LevelCore c{};
+  c.A = b.Hn + (size_t)ns * HP; c.lda = HP; c.M = ne - ns;
+  c.W = Wgm; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
+  GmEpi e{S, ns, posb, b.GMP, b.GM};
+  return launch_small<2, GmEpi, 0>(c, e, st);
+}
 
 int k_level_gru_fwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
                     const GruW& w, int HP, int prio, hipStream_t st) {
@@ -343,4 +547,13 @@ int k_level_gm_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const 
   c.W = Wgm; c.ldw = HP; c.K = HP; c.HP = HP; c.prio = prio;
   GmEpi e{S, ns, posb, b.GMP, b.GM};
   return launch_level<2>(c, e, st);
+}
+
+// unit-test surface of small_kernel's plain form (include/dvae_hip.h)
+extern "C" int dvae_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc,
+                               int M, int G, int HP, int K, int accumulate, void* stream) {
+  DVAE_REQUIRE(A && W && C, "small_gemm: null pointer");
+  DVAE_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (lda & 3) == 0 &&
+                   (ldw & 3) == 0 && (ldc & 3) == 0, "small_gemm: operands must be 16-byte aligned, strides multiples of 4");
+  return k_small_gemm(A, lda, W, ldw, w_kmajor, C, ldc, M, G, HP, K, accumulate, 0, (hipStream_t)stream);
 }

@@ -116,8 +116,8 @@ class Trainer:
                 if self.max_steps is not None and i >= self.max_steps:
                     break
                 if prepared:
-                    batch, sched = item
-                    out4 = model.loss_and_grad(batch, grad_sync=sync, sched=sched)
+                    batch, level_sched = item
+                    out4 = model.loss_and_grad(batch, grad_sync=sync, sched=level_sched)
                     opt.step()
                     sums += dp.allreduce_losses(self.dist, out4.detach().clone()).double().cpu()
                     steps += 1

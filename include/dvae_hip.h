@@ -78,6 +78,14 @@ int dvae_gemm_f32_mapped(const float* A, int lda, int a_kmajor, const float* B, 
                          float* C, int ldc, int M, int N, int K, int accumulate, const int* row_map,
                          const int* k_map, float* ws, size_t ws_bytes, void* stream);
 
+/* The product kernel of SMALL levels (<= ~1024 rows; unit-test surface): 32-row x (G x 32-column) tiles, the
+ * reduction split over the four waves of a workgroup and combined in LDS in a fixed order.
+ *   w_kmajor = 0:  C[M][G*HP] (+)= A[M][K] . W^T,  W = [G*HP][K]   (forward products, G = 1..3 gate blocks)
+ *   w_kmajor = 1:  C[M][HP]   (+)= A[M][K] . W,    W = [K][HP]     (backward products, G = 1)
+ * HP % 32 == 0, K % 16 == 0.  Same replacements as dvae_gemm_f32 (dvae_model.py:77-83,199-244). */
+int dvae_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc,
+                    int M, int G, int HP, int K, int accumulate, void* stream);
+
 /* Instrumentation for bench.py (no counterpart in the reference): while enabled
  * (dvae_gemm_profile: 1 = start a new log, 2 = resume the current log, 0 = pause),
  * every GEMM launch is bracketed by HIP events on its own stream.
@@ -256,6 +264,10 @@ int dvae_step_part2(const dvae_step* s, void* stream, void* side_stream);
  * prefix rows from the per-type table when dvae_sched_types allows it (default 1).  Every
  * combination computes the same formulas (fp32 summation order may differ). */
 int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share);
+/* tuning / test knob: per-level products of at most `rows` rows run on the small-level kernels (32-row tiles, the
+ * reduction split over the waves of a workgroup, gates fused into the forward products; default 1024, environment
+ * DVAE_SMALL_ROWS); 0 = never.  Same formulas either way (fp32 summation order differs). */
+int dvae_small_rows_tune(int rows);
 /* tuning / test knob: share of a sweep's rows whose weight-gradient products are issued on the
  * side stream while the backward sweep is still running (default 0.35; 0 = none), and the row
  * count below which a sweep has no early chunk (default 16384). */

@@ -201,3 +201,29 @@ def test_schedule_rejects_bad_graph(cuda):
     g[0, 3, 1] = 0.5       # not 0/1
     with pytest.raises(AssertionError):
         E.Schedule(g.to(cuda))
+
+
+@pytest.mark.parametrize("M,G,HP,K,km,acc", [(512, 3, 512, 512, 0, 0), (512, 2, 512, 512, 0, 0), (512, 1, 512, 1536, 1, 1),
+                                             (37, 3, 64, 64, 0, 0), (1, 1, 32, 16, 0, 1), (100, 1, 128, 384, 1, 0),
+                                             (1000, 2, 256, 272, 0, 1), (33, 1, 512, 1024, 1, 1), (700, 3, 192, 192, 0, 0)])
+def test_small_gemm(cuda, M, G, HP, K, km, acc):
+    """small_kernel's plain form (32-row tiles, K split over the four waves, LDS combine) against torch fp64:
+    forward layout (weights [G*HP][K]) and backward layout (weights [K][HP]), ragged M, K not a multiple of 64,
+    accumulate on / off; rows beyond M untouched."""
+    from dvae_amd import engine as E
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(1)
+    A = torch.randn(M, K, device=cuda)
+    N = G * HP
+    W = torch.randn(K, HP, device=cuda) if km else torch.randn(N, K, device=cuda)
+    C0 = torch.randn(M + 3, N, device=cuda)
+    C = C0.clone()
+    E.check(lib.dvae_small_gemm(E._ptr(A), A.stride(0), E._ptr(W), W.stride(0), km, E._ptr(C), C.stride(0), M, G, HP, K,
+                                acc, E._stream()))
+    torch.cuda.synchronize()
+    ref = A.double() @ (W.double() if km else W.double().t())
+    if acc:
+        ref = ref + C0[:M].double()
+    assert torch.allclose(C[:M].double(), ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
+    assert torch.equal(C[M:], C0[M:])

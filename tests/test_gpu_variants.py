@@ -56,6 +56,36 @@ def test_fused_level_kernels(cuda, bidir):
         lib.dvae_level_tune(2048, 0, 1)
 
 
+@pytest.mark.parametrize("mod,bidir,B", [(None, False, 96), (None, True, 70), ("bn", True, 45), (None, False, 1500)])
+def test_small_level_kernels(cuda, mod, bidir, B):
+    """level.hip small_kernel (32-row tiles, K split over the waves of a workgroup; gates fused forward, plain
+    accumulate backward) against the GEMM + epilogue-kernel form on the same levels: dvae_small_rows_tune(0)
+    = never, (1 << 30) = every level.  Same formulas, fp32 summation order differs."""
+    from dvae_amd import _lib
+    lib = _lib.load()
+    model, X, eps = _setup(cuda, B, bidir=bidir, mod=mod, H=501 if B < 100 and not bidir else 128)
+    try:
+        lib.dvae_small_rows_tune(0)
+        ref = _step(model, X, eps)
+        with torch.no_grad():
+            ref_states = model.encoder.node_states(X)[0].clone()
+            ref_logits = [t.clone() for t in model.decoder(eps, X)]
+        for rows in (1 << 30, 1024):
+            lib.dvae_small_rows_tune(rows)
+            out = _step(model, X, eps)
+            with torch.no_grad():
+                states = model.encoder.node_states(X)[0]
+                logits = model.decoder(eps, X)
+            close_scaled(states, ref_states, tol=1e-5, what="states, small rows %d" % rows)
+            for a, r in zip(logits, ref_logits):
+                close_scaled(a, r, tol=1e-5, what="logits, small rows %d" % rows)
+            close_scaled(out[0], ref[0], tol=1e-5, what="losses, small rows %d" % rows)
+            rel = float((out[1] - ref[1]).norm() / ref[1].norm())      # ReLU kinks: see test_fused_level_kernels
+            assert rel <= 1e-3, "gradients, small rows %d: relative L2 error %.3e" % (rows, rel)
+    finally:
+        lib.dvae_small_rows_tune(1024)
+
+
 def test_prepared_schedule_bitwise(cuda):
     model, X, eps = _setup(cuda, 64)
     ref = _step(model, X, eps)
