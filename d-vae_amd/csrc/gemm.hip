@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <deque>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -158,6 +159,150 @@ struct Tile {
   }
 };
 
+
+// ---------------------------------------------------------------------------
+// fp32 products on the bf16 matrix pipe ("x6" core).  CDNA4 retires v_mfma_f32_32x32x16_bf16 in 32 cycles and
+// v_mfma_f32_32x32x2_f32 in 64: sixteen times the multiply-adds per clock.  An fp32 value splits EXACTLY into
+// three bf16 pieces (x = x1 + x2 + x3: truncation keeps 8 significand bits per piece, 24 in all), a bf16 x bf16
+// product is exact in the fp32 accumulator, and of the nine piece products the six with i + j <= 4
+//     a1b1, a1b2, a2b1, a1b3, a2b2, a3b1
+// carry everything above 2^-24 |a b|, which is fp32's own rounding step (the dropped a2b3 + a3b2 + a3b3 are
+// ~2^-25 |a b| on average).  So six bf16 MFMAs give the fp32 product at 16 / 6 = 2.7 x the fp32 MFMA rate, with
+// fp32 accumulation as before.  Operands are split while they are staged into LDS (5.5 VALU operations per
+// element, once per k-tile) and kept as three planes of bf16 in the layout the 32x32x16 fragment read wants:
+//     plane[p][k-octet o][row r] = 8 bf16 (16 bytes) = pieces p of k = 8o .. 8o+7 of row r
+// so a lane's fragment is one ds_read_b128 and 16 lanes of a read group touch 16 consecutive 16-byte slots.
+// A k-major operand ([k][m] in memory) is transposed in registers on the way: a thread loads NV consecutive
+// k rows of 4 consecutive m and writes, per m, NV consecutive k.
+// ---------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct Split3 { unsigned p1, p2, p3; };   // bf16 pieces in the HIGH halves
+__device__ __forceinline__ Split3 split3(float x) {
+  Split3 s;
+  s.p1 = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(s.p1);
+  s.p2 = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(s.p2);
+  s.p3 = __float_as_uint(r2);
+  return s;
+}
+// (high half of lo) | (high half of hi) << 16
+__device__ __forceinline__ unsigned pack_hi(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+template <int KM, int ROWS>
+struct XTile {
+  static constexpr int BK = 32;
+  static constexpr int NV = ROWS / 32;              // float4 per thread
+  static constexpr int KGN = 32 / NV;               // k-major: groups of NV consecutive k
+  static constexpr int RQ = ROWS / 4;
+  static constexpr int ROWSP = ROWS + (KM ? 1 : 2); // 16-byte slots per k-octet (the pad spreads the staging stores over the banks)
+  static constexpr int PLANE = 4 * ROWSP * 16;      // bytes
+  static constexpr int LDS_FLOATS = 3 * PLANE / 4;
+  static_assert(NV >= 1 && NV <= 4, "x6 tiles: 32..128 rows");
+  float4 v[NV];
+  size_t ro[NV];
+  int kq[NV];
+
+  __device__ __forceinline__ void rows_init(int ld, int r0, int rows, const int* __restrict__ map, int tid) {
+    if (KM == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int r = min(r0 + tid / 8 + i * 32, rows - 1);
+        ro[i] = (size_t)(map ? map[r] : r) * ld;
+      }
+    }
+  }
+  __device__ __forceinline__ void kq_fetch(const int* __restrict__ kmap, int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) kq[i] = kmap[min(k0 + (tid % KGN) * NV + i, kend - 1)];
+  }
+  __device__ __forceinline__ void load_gathered(const float* __restrict__ P, int ld, int r0, int rows, int tid) {
+    const int r = min(r0 + (tid / KGN) * 4, rows - 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(P + (size_t)kq[i] * ld + r);
+  }
+  __device__ __forceinline__ void load_gathered_checked(const float* __restrict__ P, int ld, int r0, int rows, int k0,
+                                                        int kend, const int* __restrict__ kmap, int tid) {
+    const int r = r0 + (tid / KGN) * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int k = k0 + (tid % KGN) * NV + i;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < kend && r < rows) val = *reinterpret_cast<const float4*>(P + (size_t)kmap[k] * ld + r);
+      v[i] = val;
+    }
+  }
+  template <bool CHECK>
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int rows, int k0, int kend, int tid) {
+    if (KM == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int k = k0 + (tid % 8) * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!CHECK || (r0 + tid / 8 + i * 32 < rows && k < kend)) val = *reinterpret_cast<const float4*>(P + ro[i] + k);
+        v[i] = val;
+      }
+    } else {
+      const int rr = r0 + (tid / KGN) * 4;
+      const int r = CHECK ? rr : min(rr, rows - 4);
+      const float* base = P + (size_t)(k0 + (tid % KGN) * NV) * ld + r;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!CHECK || (k0 + (tid % KGN) * NV + i < kend && rr < rows)) val = *reinterpret_cast<const float4*>(base + (size_t)i * ld);
+        v[i] = val;
+      }
+    }
+  }
+
+  // split into bf16 pieces and stage: lds -> three planes
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+    char* base = reinterpret_cast<char*>(lds);
+    if (KM == 0) {
+      const int kq4 = tid % 8;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int row = tid / 8 + i * 32;
+        const Split3 a = split3(v[i].x), b = split3(v[i].y), c = split3(v[i].z), d = split3(v[i].w);
+        char* q = base + ((kq4 >> 1) * ROWSP + row) * 16 + (kq4 & 1) * 8;
+        *reinterpret_cast<uint2*>(q) = make_uint2(pack_hi(a.p1, b.p1), pack_hi(c.p1, d.p1));
+        *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(pack_hi(a.p2, b.p2), pack_hi(c.p2, d.p2));
+        *reinterpret_cast<uint2*>(q + 2 * PLANE) = make_uint2(pack_hi(a.p3, b.p3), pack_hi(c.p3, d.p3));
+      }
+    } else {
+      const int kg = tid % KGN, mq = tid / KGN;
+      const int kk = kg * NV;   // first of this thread's NV consecutive k
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        Split3 s[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s[i] = split3(c == 0 ? v[i].x : c == 1 ? v[i].y : c == 2 ? v[i].z : v[i].w);
+        char* q = base + ((kk >> 3) * ROWSP + mq * 4 + c) * 16 + (kk & 7) * 2;
+        if (NV == 4) {
+          *reinterpret_cast<uint2*>(q) = make_uint2(pack_hi(s[0].p1, s[1].p1), pack_hi(s[2].p1, s[3].p1));
+          *reinterpret_cast<uint2*>(q + PLANE) = make_uint2(pack_hi(s[0].p2, s[1].p2), pack_hi(s[2].p2, s[3].p2));
+          *reinterpret_cast<uint2*>(q + 2 * PLANE) = make_uint2(pack_hi(s[0].p3, s[1].p3), pack_hi(s[2].p3, s[3].p3));
+        } else if (NV == 2) {
+          *reinterpret_cast<unsigned*>(q) = pack_hi(s[0].p1, s[NV - 1].p1);
+          *reinterpret_cast<unsigned*>(q + PLANE) = pack_hi(s[0].p2, s[NV - 1].p2);
+          *reinterpret_cast<unsigned*>(q + 2 * PLANE) = pack_hi(s[0].p3, s[NV - 1].p3);
+        } else {
+          *reinterpret_cast<unsigned short*>(q) = (unsigned short)(s[0].p1 >> 16);
+          *reinterpret_cast<unsigned short*>(q + PLANE) = (unsigned short)(s[0].p2 >> 16);
+          *reinterpret_cast<unsigned short*>(q + 2 * PLANE) = (unsigned short)(s[0].p3 >> 16);
+        }
+      }
+    }
+  }
+
+  // piece p of the 32-row sub-tile at rbase, k-step ks (16 wide): lane holds k = 16 ks + 8 (lane>>5) + 0..7 of row lane&31
+  static __device__ __forceinline__ bf16x8 frag(const float* lds, int p, int rbase, int ks, int lane) {
+    const char* q = reinterpret_cast<const char*>(lds) + p * PLANE + ((ks * 2 + (lane >> 5)) * ROWSP + rbase + (lane & 31)) * 16;
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q));
+  }
+};
+
 struct GemmParams {
   const float* A; const float* B; float* C; const float* bias;
   int lda, ldb, ldc;
@@ -182,13 +327,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + j;
 }
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2, bool KG = false>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2, bool KG = false, bool X6 = false>
 __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   static_assert(!KG || (AKM == 1 && BKM == 1), "a gathered reduction needs two k-major operands");
+  static_assert(!X6 || BK == 32, "the x6 core stages 32-wide k-tiles");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static_assert(WM * WN == 4, "four waves per workgroup");
-  using TA = Tile<AKM, BM, BK>;
-  using TB = Tile<BKM, BN, BK>;
+  using TA = typename std::conditional<X6, XTile<AKM, BM>, Tile<AKM, BM, BK>>::type;
+  using TB = typename std::conditional<X6, XTile<BKM, BN>, Tile<BKM, BN, BK>>::type;
   // ST = 1: one LDS stage, two barriers per k-tile.  ST = 2: two stages, one barrier per
   // k-tile -- a wave refills the other stage as soon as its own MFMAs of this tile are issued.
   constexpr int STAGE = TA::LDS_FLOATS + TB::LDS_FLOATS;
@@ -237,6 +383,32 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   auto compute = [&]() {
     const float* As = lds + cur * STAGE;
     const float* Bs = As + TA::LDS_FLOATS;
+    if constexpr (X6) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) af[i][q] = TA::frag(As, q, wm * (BM / WM) + i * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) bf[j][q] = TB::frag(Bs, q, wn * (BN / WN) + j * 32, ks, lane);
+        // the six piece products with i + j <= 4, small ones first; n-operand first as below (C^T in the accumulator)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][2], af[i][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][0], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
 #pragma unroll
     for (int kc = 0; kc < BK / 8; ++kc) {
       float4 af[TM], bf[TN];
@@ -255,6 +427,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j].z, af[i].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j].w, af[i].w, acc[i][j], 0, 0, 0);
         }
+    }
     }
   };
   auto refill = [&]() {   // registers -> LDS for the next k-tile
@@ -420,7 +593,7 @@ void gemm_prof_end(void* h, hipStream_t st) { prof_end(static_cast<GemmProf*>(h)
 
 namespace {
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1, int MINB = 2, bool KG = false>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1, int MINB = 2, bool KG = false, bool X6 = false>
 int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   GemmParams p;
   p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias;
@@ -463,7 +636,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     p.c_split = 0;
   }
   GemmProf* pr = prof_begin(AKM * 2 + BKM, 2.0 * d.M * d.N * d.K, stream);
-  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST, MINB, KG>), dim3(p.nblk, splits), dim3(256),
+  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST, MINB, KG, X6>), dim3(p.nblk, splits), dim3(256),
                      0, stream, p);
   prof_end(pr, stream);
   DVAE_LAUNCH_CHECK();
@@ -489,6 +662,9 @@ extern "C" int dvae_gemm_tune(int splitk_blocks, int force_prio) {
   g_force_prio = force_prio;
   return DVAE_OK;
 }
+// 1: fp32 products as six bf16 MFMAs on split operands (the x6 core above); 0: v_mfma_f32_32x32x2_f32
+static int g_x6 = getenv("DVAE_GEMM_X6") ? atoi(getenv("DVAE_GEMM_X6")) : 0;
+extern "C" int dvae_gemm_x6(int on) { g_x6 = on; return DVAE_OK; }
 static int g_force_tile = 0;   // tuning knob (tests/bench_gemm.py): 0 auto, 1 128x128, 2 64x128, 3 64x64
 extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE_OK; }
 
@@ -501,6 +677,7 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
     // gathered reduction rows: the weight-gradient shape only (TN, 128x128 tiles, split K)
     DVAE_REQUIRE(d.a_kmajor && d.b_kmajor && (d.M & 3) == 0 && (d.N & 3) == 0 && d.N > 32,
                  "gemm: a reduction map needs two k-major operands and N > 32");
+    if (g_x6) return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true>(d, ws, ws_bytes, stream);
     return launch<1, 1, 128, 128, 2, 2, 16, 1, 2, true>(d, ws, ws_bytes, stream);
   }
   DVAE_REQUIRE(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0, "gemm: operands must be 16-byte aligned");
@@ -534,6 +711,13 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
     }
   }
 #define GEMM_PICK(AK, BKK)                                                                   \
+  if (g_x6) {                                                                                \
+    if (narrow) return launch<AK, BKK, 128, 32, 4, 1, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);   \
+    if (flat) return launch<AK, BKK, 32, 128, 1, 4, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);     \
+    if (quarter) return launch<AK, BKK, 64, 64, 2, 2, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);   \
+    return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 1, 2, false, true>(d, ws, ws_bytes, stream)         \
+                : launch<AK, BKK, 128, 128, 2, 2, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);       \
+  }                                                                                          \
   if (narrow) return launch<AK, BKK, 128, 32, 4, 1>(d, ws, ws_bytes, stream);                \
   if (flat) return launch<AK, BKK, 32, 128, 1, 4>(d, ws, ws_bytes, stream);                  \
   if (quarter) return launch<AK, BKK, 64, 64, 2, 2>(d, ws, ws_bytes, stream);                \

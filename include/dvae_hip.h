@@ -96,6 +96,12 @@ int dvae_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmaj
 int dvae_gemm_force_tile(int mode);   /* tuning knob: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
 int dvae_gemm_force_splits(int v);     /* lab knob: split-K factor of every launch (0 = automatic) */
 int dvae_gemm_variant(int v);          /* lab knob: force a tile shape (0 = automatic) */
+/* arithmetic core of dvae_gemm_f32 and of every product the entry points below launch through it:
+ * 0 = v_mfma_f32_32x32x2_f32; 1 = each fp32 operand split exactly into three bf16 pieces while it is staged,
+ * the product formed from the six piece products above 2^-24 |a b| on v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation (fp32-accurate, 16/6 of the fp32 MFMA rate).  Environment: DVAE_GEMM_X6.  Same replacements
+ * as dvae_gemm_f32. */
+int dvae_gemm_x6(int on);
 int dvae_gemm_dbg(int bits);           /* lab knob: 1 skip the epilogue stores, 2 skip reloads (timing ablations) */
 int dvae_gemm_tune(int splitk_blocks, int force_prio);   /* tuning knobs: workgroups a split-K launch aims for
                                                            (0 = keep), wave priority override (-1 = caller's) */

@@ -9,6 +9,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1], ids=["f32mfma", "bf16x6"])
+def core(request):
+    """Both arithmetic cores of the GEMM: v_mfma_f32_32x32x2_f32, and six bf16 MFMAs on operands split into three
+    bf16 pieces (gemm.hip, the x6 core)."""
+    from dvae_amd._lib import load
+    lib = load()
+    lib.dvae_gemm_x6(request.param)
+    yield request.param
+    lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "0")))
+
+
 def _gemm(lib, A, a_km, Bm, b_km, M, N, K, bias=None, relu=0, acc=None, ws_mb=64):
     from dvae_amd import engine as E
     dev = A.device
@@ -23,7 +34,7 @@ def _gemm(lib, A, a_km, Bm, b_km, M, N, K, bias=None, relu=0, acc=None, ws_mb=64
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (4096, 1536, 512), (1000, 1024, 512), (37, 32, 1024),
                                    (300, 2048, 64), (5, 128, 2048), (64, 512, 1024), (100, 512, 2048),
                                    (64, 128, 1024), (48, 1536, 512)])
-def test_gemm_nt(cuda, M, N, K):
+def test_gemm_nt(cuda, M, N, K, core):
     from dvae_amd._lib import load
     lib = load()
     torch.manual_seed(0)
@@ -48,7 +59,7 @@ def _gemm_mapped(lib, A, a_km, Bm, b_km, C, M, N, K, acc=0, row_map=None, k_map=
 
 @pytest.mark.parametrize("rows,M,N,K,b_km", [(3000, 1000, 512, 2048, 1), (3000, 1000, 2048, 512, 0),
                                              (500, 77, 96, 36, 0), (200, 200, 512, 1536, 1), (64, 1, 128, 64, 1)])
-def test_gemm_row_map(cuda, rows, M, N, K, b_km):
+def test_gemm_row_map(cuda, rows, M, N, K, b_km, core):
     """Product over a scattered subset of rows: reads A[map[m]], writes C[map[m]], leaves the other rows alone."""
     from dvae_amd._lib import load
     lib = load()
@@ -72,7 +83,7 @@ def test_gemm_row_map(cuda, rows, M, N, K, b_km):
 
 @pytest.mark.parametrize("rows,K,M,N", [(9000, 5003, 2048, 512), (300, 123, 128, 64), (40, 16, 512, 512),
                                         (5000, 4096, 1536, 128), (100, 1, 64, 64)])
-def test_gemm_k_map(cuda, rows, K, M, N):
+def test_gemm_k_map(cuda, rows, K, M, N, core):
     """Weight-gradient shape summed over a scattered subset of rows (ragged K, split K)."""
     from dvae_amd._lib import load
     lib = load()
@@ -88,7 +99,7 @@ def test_gemm_k_map(cuda, rows, K, M, N):
     assert torch.allclose(C.double(), 2 * ref, rtol=1e-5, atol=2e-4 * K ** 0.5)
 
 
-def test_gemm_asymmetric_exact(cuda):
+def test_gemm_asymmetric_exact(cuda, core):
     """A = I with an asymmetric integer B catches swapped row/col maps."""
     from dvae_amd._lib import load
     lib = load()
@@ -100,7 +111,7 @@ def test_gemm_asymmetric_exact(cuda):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 1536), (777, 512, 1024), (64, 1024, 32), (130, 512, 2048), (24, 512, 1024), (32, 2048, 512)])
-def test_gemm_nn(cuda, M, N, K):
+def test_gemm_nn(cuda, M, N, K, core):
     from dvae_amd._lib import load
     lib = load()
     torch.manual_seed(1)
@@ -116,7 +127,7 @@ def test_gemm_nn(cuda, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(1536, 512, 4096), (2048, 512, 90000), (32, 1024, 5000), (1024, 512, 333),
                                    (512, 64, 4096)])
-def test_gemm_tn(cuda, M, N, K):
+def test_gemm_tn(cuda, M, N, K, core):
     from dvae_amd._lib import load
     lib = load()
     torch.manual_seed(2)
@@ -125,6 +136,41 @@ def test_gemm_tn(cuda, M, N, K):
     ref = dY.double().t() @ X.double()
     out = _gemm(lib, dY, 1, X, 1, M, N, K)
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=2e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+def test_gemm_x6_is_fp32_accurate(cuda, form):
+    """The split-operand core drops only piece products below 2^-24 |a b|: against an fp64 product its error is that
+    of the fp32 MFMA core (same fp32 accumulation), nowhere near bf16's 2^-8."""
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(5)
+    M, N, K = 1024, 512, 2048
+    # wide dynamic range inside every row: pieces of very different magnitude meet in one accumulator
+    scale = lambda *s: torch.randn(*s, device=cuda) * torch.exp2(torch.randint(-6, 7, s, device=cuda).float())
+    if form == "nt":
+        A, W = scale(M, K), scale(N, K)
+        ref, args = A.double() @ W.double().t(), (A, 0, W, 0)
+        mag = A.abs().double() @ W.abs().double().t()
+    elif form == "nn":
+        A, W = scale(M, K), scale(K, N)
+        ref, args = A.double() @ W.double(), (A, 0, W, 1)
+        mag = A.abs().double() @ W.abs().double()
+    else:
+        A, W = scale(K, M), scale(K, N)
+        ref, args = A.double().t() @ W.double(), (A, 1, W, 1)
+        mag = A.abs().double().t() @ W.abs().double()
+    err = {}
+    try:
+        for core_id in (0, 1):
+            lib.dvae_gemm_x6(core_id)
+            out = _gemm(lib, *args, M, N, K)
+            err[core_id] = float(((out.double() - ref).abs() / mag).max())     # relative to sum |a||b|: the fp32 bound's scale
+    finally:
+        lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "0")))
+    print("max |err| / sum|a||b|: fp32 MFMA %.2e, bf16x6 %.2e" % (err[0], err[1]))
+    assert err[0] < 2e-6 and err[1] < 2e-6, err
+    assert err[1] < 4 * err[0] + 1e-7, err
 
 
 @pytest.mark.parametrize("B,N,p,ragged", [(64, 8, 0.5, False), (33, 20, 0.2, False), (16, 128, 0.05, False),

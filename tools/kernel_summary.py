@@ -22,3 +22,11 @@ for (n, q), v in agg.items():
 print('# per queue (launches, busy ms per step):', {q: (v[0] // nst, round(v[1] / nst / 1e6, 2)) for q, v in qs.items()})
 for (n, q), v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
     print('%-78s q%s n=%4d avg %7.1f us  %8.1f us/step' % (n, q, v[0] // nst, v[1] / v[0] / 1e3, v[1] / nst / 1e3))
+# gaps between consecutive launches of the busiest queue (the per-level chain): idle time a launch waits for
+busiest = max(qs, key=lambda q: qs[q][1])
+ch = [r for r in rows[a:b] if r['Queue_Id'] == busiest]
+gaps = [int(ch[i + 1]['Start_Timestamp']) - int(ch[i]['End_Timestamp']) for i in range(len(ch) - 1)]
+gaps = [g for g in gaps if g < 200000]   # step boundaries (host work) aside
+pos = [g for g in gaps if g > 0]
+print('# queue %s: %d launches/step, gaps > 0: %d/step, mean %.2f us, total %.2f ms/step' % (
+    busiest, len(ch) // nst, len(pos) // nst, sum(pos) / max(1, len(pos)) / 1e3, sum(pos) / nst / 1e6))
