@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 
 H, Z = 501, 56
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16, v_mfma_f32_32x32x16_bf16 at 32 cycles
+# the default GEMM core forms every fp32 product from SIX bf16 MFMAs on exactly split operands (gemm.hip, "x6"):
+# its roof in fp32-equivalent FLOP/s is the bf16 peak / 6
+PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E
 PROF_EVERY = 4                   # timed steps between two steps whose GEMM launches carry HIP events
 
@@ -438,10 +442,17 @@ def main():
             algo = per_dag * B_local * prof_steps
             busy = gemm[6] if gemm[6] > 0 else kms     # wall time with >= 1 GEMM launch running
             ach = algo / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
+            x6 = bool(lib.dvae_gemm_core())
+            peak = PEAK_X6_TFLOPS if x6 else PEAK_F32_MFMA_TFLOPS
             res["roofline"] = {
-                "bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-                "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "bound": "mfma",
+                "kernel": "gemm_f32_kernel, x6 core (fp32 operands split exactly into 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 "
+                          "per product, fp32 accumulate)" if x6 else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None,
+                "peak_is": "dense bf16 MFMA peak 2500 TFLOP/s / 6 bf16 products per fp32 product" if x6
+                           else "dense fp32 MFMA peak",
+                "frac_of_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                 "launches_per_step": launches / prof_steps, "kernel_busy_ms_per_step": busy / prof_steps,
                 "sum_launch_ms_per_step": kms / prof_steps, "timed_steps_with_events": prof_steps,
                 "avg_launch_us": kms / max(launches, 1) * 1e3,

@@ -75,6 +75,9 @@ struct GemmDesc {
 // C[M][N] (+)= sum_k A(m,k) * B(n,k).  ws/ws_bytes: scratch for split-K (may be null).
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream);
 
+// arithmetic core in use (gemm.hip): 1 = fp32 products as six bf16 MFMAs on split operands, 0 = fp32 MFMA
+int gemm_x6_enabled();
+
 // bench.py's per-launch timing hooks (gemm.hip); begin returns NULL when profiling is off
 void* gemm_prof_begin(double flops, hipStream_t st);
 void gemm_prof_end(void* h, hipStream_t st);

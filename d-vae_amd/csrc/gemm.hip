@@ -662,9 +662,11 @@ extern "C" int dvae_gemm_tune(int splitk_blocks, int force_prio) {
   g_force_prio = force_prio;
   return DVAE_OK;
 }
-// 1: fp32 products as six bf16 MFMAs on split operands (the x6 core above); 0: v_mfma_f32_32x32x2_f32
-static int g_x6 = getenv("DVAE_GEMM_X6") ? atoi(getenv("DVAE_GEMM_X6")) : 0;
+// 1 (default): fp32 products as six bf16 MFMAs on split operands (the x6 core above); 0: v_mfma_f32_32x32x2_f32
+static int g_x6 = getenv("DVAE_GEMM_X6") ? atoi(getenv("DVAE_GEMM_X6")) : 1;
 extern "C" int dvae_gemm_x6(int on) { g_x6 = on; return DVAE_OK; }
+extern "C" int dvae_gemm_core(void) { return g_x6; }
+int gemm_x6_enabled() { return g_x6; }
 static int g_force_tile = 0;   // tuning knob (tests/bench_gemm.py): 0 auto, 1 128x128, 2 64x128, 3 64x64
 extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE_OK; }
 

@@ -99,9 +99,10 @@ int dvae_gemm_variant(int v);          /* lab knob: force a tile shape (0 = auto
 /* arithmetic core of dvae_gemm_f32 and of every product the entry points below launch through it:
  * 0 = v_mfma_f32_32x32x2_f32; 1 = each fp32 operand split exactly into three bf16 pieces while it is staged,
  * the product formed from the six piece products above 2^-24 |a b| on v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation (fp32-accurate, 16/6 of the fp32 MFMA rate).  Environment: DVAE_GEMM_X6.  Same replacements
+ * accumulation (fp32-accurate, 16/6 of the fp32 MFMA rate).  Default 1; environment: DVAE_GEMM_X6.  Same replacements
  * as dvae_gemm_f32. */
 int dvae_gemm_x6(int on);
+int dvae_gemm_core(void);              /* the core in use: 1 = bf16 x6 (default), 0 = fp32 MFMA */
 int dvae_gemm_dbg(int bits);           /* lab knob: 1 skip the epilogue stores, 2 skip reloads (timing ablations) */
 int dvae_gemm_tune(int splitk_blocks, int force_prio);   /* tuning knobs: workgroups a split-K launch aims for
                                                            (0 = keep), wave priority override (-1 = caller's) */
@@ -265,7 +266,8 @@ int dvae_step_part2(const dvae_step* s, void* stream, void* side_stream);
 
 /* Tuning / test knob of the forward level sweep (no counterpart in the reference): node rows
  * per level from which the gate/map step runs as ONE fused launch (GEMM + sigmoid*map
- * epilogue; -1 never, 0 always, default 2048) and whether the GRU step runs fused (hidden
+ * epilogue; -1 never, 0 always, -2 = default: 2048 beside the fp32-MFMA GEMM core, never beside the x6 core)
+ * and whether the GRU step runs fused (hidden
  * GEMM + gates in one launch; default 0); type_share: whether the decoder serves its type-only
  * prefix rows from the per-type table when dvae_sched_types allows it (default 1).  Every
  * combination computes the same formulas (fp32 summation order may differ). */

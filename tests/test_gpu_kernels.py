@@ -17,7 +17,7 @@ def core(request):
     lib = load()
     lib.dvae_gemm_x6(request.param)
     yield request.param
-    lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "0")))
+    lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "1")))
 
 
 def _gemm(lib, A, a_km, Bm, b_km, M, N, K, bias=None, relu=0, acc=None, ws_mb=64):
@@ -167,7 +167,7 @@ def test_gemm_x6_is_fp32_accurate(cuda, form):
             out = _gemm(lib, *args, M, N, K)
             err[core_id] = float(((out.double() - ref).abs() / mag).max())     # relative to sum |a||b|: the fp32 bound's scale
     finally:
-        lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "0")))
+        lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "1")))
     print("max |err| / sum|a||b|: fp32 MFMA %.2e, bf16x6 %.2e" % (err[0], err[1]))
     assert err[0] < 2e-6 and err[1] < 2e-6, err
     assert err[1] < 4 * err[0] + 1e-7, err

@@ -53,7 +53,7 @@ def test_fused_level_kernels(cuda, bidir):
             rel = float((out[1] - ref[1]).norm() / ref[1].norm())
             assert rel <= 1e-3, "gradients %d/%d: relative L2 error %.3e" % (gm_min, gru, rel)
     finally:
-        lib.dvae_level_tune(2048, 0, 1)
+        lib.dvae_level_tune(-2, 0, 1)
 
 
 @pytest.mark.parametrize("mod,bidir,B", [(None, False, 96), (None, True, 70), ("bn", True, 45), (None, False, 1500)])
@@ -117,12 +117,12 @@ def test_type_shared_rows_match_per_row(cuda, mod):
     model, X, eps = _setup(cuda, 300, mod=mod, H=501 if mod is None else 128)
     assert model._schedule(X).onehot
     try:
-        lib.dvae_level_tune(2048, 0, 0)
+        lib.dvae_level_tune(-2, 0, 0)
         ref = _step(model, X, eps)
-        lib.dvae_level_tune(2048, 0, 1)
+        lib.dvae_level_tune(-2, 0, 1)
         out = _step(model, X, eps)
     finally:
-        lib.dvae_level_tune(2048, 0, 1)
+        lib.dvae_level_tune(-2, 0, 1)
     close_scaled(out[0], ref[0], tol=1e-5, what="losses")
     rel = float((out[1] - ref[1]).norm() / ref[1].norm())      # ReLU kinks: see test_fused_level_kernels
     assert rel <= 1e-3, "gradients: relative L2 error %.3e" % rel
