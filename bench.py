@@ -246,6 +246,7 @@ def main():
                     help="lab: the decoder's Adam as an instance of its own, stepped on the side stream as soon as its "
                          "gradients are final (under the encoder's backward); measured 0.07-0.1 ms SLOWER than one "
                          "fused Adam after the step at B = 512 ... 4096, so it is not the default")
+    ap.add_argument("--no-core-ab", action="store_true", help="N = 1: skip the few steps on the fp32-MFMA GEMM core after the timed region")
     ap.add_argument("--no-weak-probe", action="store_true", help="N > 1: skip the fixed-per-GPU-batch probe after the timed region")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: ranks rendezvous over gloo, rank 0 prints the line")
@@ -374,6 +375,23 @@ def main():
         buf = (ctypes.c_double * 12)()
         _lib.check(lib.dvae_gemm_profile_read(ctypes.cast(buf, ctypes.c_void_p)))
         gemm = list(buf)
+    # N = 1: the same step on the OTHER arithmetic core of the GEMM (v_mfma_f32_32x32x2_f32 instead of the default
+    # six bf16 MFMAs on exactly split fp32 operands), a few steps right after the timed region, reported beside `value`
+    fp32_core = None
+    if world == 1 and lib.dvae_gemm_core() and not args.no_core_ab:
+        lib.dvae_gemm_x6(0)
+        for i in range(2):
+            step(5000 + i)
+        barrier()
+        n2 = max(3, min(10, args.steps))
+        t2 = time.perf_counter()
+        for i in range(n2):
+            step(5002 + i)
+        barrier()
+        t2 = time.perf_counter() - t2
+        lib.dvae_gemm_x6(1)
+        fp32_core = {"core": "v_mfma_f32_32x32x2_f32", "steps": n2, "ms_per_step": t2 / n2 * 1e3,
+                     "value": B_global * n2 / t2, "unit": "DAGs/s"}
     rccl_ranks = None
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -430,6 +448,12 @@ def main():
             res["rccl_ranks"] = rccl_ranks
         if weak_probe is not None:
             res["weak_scaling_probe"] = weak_probe
+        res["gemm_core"] = ("bf16 x6: fp32 operands split exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per "
+                            "product, fp32 accumulation; error against fp64 no larger than the fp32 MFMA's "
+                            "(tests/test_gpu_kernels.py::test_gemm_x6_is_fp32_accurate)" if lib.dvae_gemm_core()
+                            else "fp32 MFMA (v_mfma_f32_32x32x2_f32)")
+        if fp32_core is not None:
+            res["same_step_on_fp32_mfma_core"] = fp32_core
         if gemm is not None:
             # dominant kernel: gemm_f32_kernel (all three layouts are one template)
             launches = gemm[0] + gemm[3] + gemm[9]
