@@ -26,8 +26,7 @@ struct LevelCfg {
   int small_rows = getenv("DVAE_SMALL_ROWS") ? atoi(getenv("DVAE_SMALL_ROWS")) : 1024;
   LevelCfg() {
     type_share = getenv("DVAE_NO_TYPE_SHARE") ? 0 : 1;
-    // -2 = automatic: from 2048 rows up beside the fp32-MFMA GEMM core; never beside the x6 core, whose plain GEMM +
-    // epilogue kernel is faster than the fused kernel's fp32 MFMA loop (profiles/r02_x6_gemm.txt)
+    // -2 = automatic: from 2048 rows up (the fused kernel runs on the arithmetic core the GEMM uses, level.hip)
     fused_gm_min_rows = getenv("DVAE_UNFUSED") ? -1 : getenv("DVAE_FUSED_GM_MIN") ? atoi(getenv("DVAE_FUSED_GM_MIN")) : -2;
     // 0: hidden GEMM + gate kernel; 1: fused hidden GEMM + gates; 2: node sweeps run aggregation + hidden GEMM +
     // gates as ONE launch (level.hip GATHER kernels), everything else as 0
@@ -321,7 +320,7 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   // dvae_level_tune / DVAE_FUSED_GRU=1.
   const bool fused_gru = g_level_cfg.fused_gru == 1;
   const bool gather_gru = g_level_cfg.fused_gru == 2 && !b.prefix && d.mod == 0;
-  const int fused_gm_min = g_level_cfg.fused_gm_min_rows != -2 ? g_level_cfg.fused_gm_min_rows : gemm_x6_enabled() ? -1 : 2048;
+  const int fused_gm_min = g_level_cfg.fused_gm_min_rows != -2 ? g_level_cfg.fused_gm_min_rows : 2048;
   static const bool fold_partials = getenv("DVAE_NO_FOLD") == nullptr;   // A-B tests: combine launch instead
   const int small_rows = g_level_cfg.small_rows;
   auto gru_rows = [&](int p0, int p1) -> int {

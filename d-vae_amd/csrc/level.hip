@@ -14,6 +14,7 @@
 // Same MFMA (v_mfma_f32_32x32x2_f32) and the same gate formulas as gemm.hip +
 // kernels.hip; the fp32 summation order differs only where the plain GEMM splits K.
 #include "kernels.h"
+#include "x6.h"
 
 namespace {
 
@@ -289,6 +290,102 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
   }
 }
 
+// The same fused level step on the x6 arithmetic core (x6.h: operands split exactly into three bf16 pieces while staged,
+// six v_mfma_f32_32x32x16_bf16 per fp32 product): k-tile 32, both operands m-major, the weight tile's LDS row is
+// gate * 64 + hidden unit as above, so the epilogues are shared.
+template <int G, int TM, class Epi>
+__global__ __launch_bounds__(256, 2) void level_x6_kernel(LevelCore p, Epi e) {
+  constexpr int BM = 64 * TM;
+  using TA = XTile<0, BM>;
+  using TB = XTile<0, G * BNG>;
+  __shared__ __attribute__((aligned(16))) float lds[TA::LDS_FLOATS + TB::LDS_FLOATS];
+  float* As = lds;
+  float* Bs = lds + TA::LDS_FLOATS;
+
+  if (p.prio) __builtin_amdgcn_s_setprio(2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, p.nblk);
+  const int m0 = (tile / p.tiles_n) * BM;
+  const int n0 = (tile % p.tiles_n) * BNG;
+
+  f32x16 acc[TM][G];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][g][r] = 0.f;
+
+  TA ta;
+  TB tb;
+  ta.rows_init(p.lda, m0, p.M, nullptr, tid);   // rows beyond M clamp to the last one (never stored)
+#pragma unroll
+  for (int i = 0; i < TB::NV; ++i) {
+    const int row = tid / 8 + i * 32;            // LDS row = gate * 64 + hidden unit
+    tb.ro[i] = ((size_t)(row / BNG) * p.HP + n0 + row % BNG) * p.ldw;
+  }
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[TM][3], bf[G][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) af[i][q] = TA::frag(As, q, wm * (BM / 2) + i * 32, ks, lane);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bf[g][q] = TB::frag(Bs, q, g * BNG + wn * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          // the six piece products with i + j <= 4, small ones first; n-operand first (C^T in the accumulator)
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][0], af[i][2], acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][2], af[i][0], acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][1], af[i][1], acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][0], af[i][1], acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][1], af[i][0], acc[i][g], 0, 0, 0);
+          acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[g][0], af[i][0], acc[i][g], 0, 0, 0);
+        }
+    }
+  };
+  // K is a multiple of 32 (HP is a multiple of 64): no load needs a predicate
+  ta.template load<false>(p.A, p.lda, m0, p.M, 0, p.K, tid);
+  tb.template load<false>(p.W, p.ldw, 0, 0, 0, p.K, tid);
+  ta.store(As, tid);
+  tb.store(Bs, tid);
+  __syncthreads();
+  for (int k0 = 0; k0 + 32 < p.K; k0 += 32) {
+    ta.template load<false>(p.A, p.lda, m0, p.M, k0 + 32, p.K, tid);
+    tb.template load<false>(p.W, p.ldw, 0, 0, k0 + 32, p.K, tid);
+    compute();
+    __syncthreads();
+    ta.store(As, tid);
+    tb.store(Bs, tid);
+    __syncthreads();
+  }
+  compute();
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    const auto rw = row_meta(e, p.HP, m);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = n0 + wn * 32 + 8 * q + 4 * (lane >> 5);
+      float4 v[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        v[g] = make_float4(acc[i][g][4 * q], acc[i][g][4 * q + 1], acc[i][g][4 * q + 2], acc[i][g][4 * q + 3]);
+      epilogue(e, p.HP, rw, col, v, nullptr);
+    }
+  }
+}
+
+
 // ---------------------------------------------------------------------------
 // Small levels (<= ~1024 rows: the per-GPU shard of a strong-scaled batch, config 1, the thin deep levels of
 // large graphs).  There a 64-row tile grid leaves most CUs empty and every workgroup walks the whole reduction
@@ -448,15 +545,19 @@ __global__ __launch_bounds__(256) void small_kernel(LevelCore p, Epi e) {
 template <int G, class Epi, bool GATHER = false>
 int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
   c.tiles_n = c.HP / BNG;
-  const bool big = (long long)cdiv(c.M, 128) * c.tiles_n >= 512;
+  const bool x6 = !GATHER && gemm_x6_enabled() && c.K % 32 == 0;
+  // 128-row tiles once they still give every CU two workgroups (the three-gate x6 tile of 128 rows would spill: 64 rows)
+  const bool big = (long long)cdiv(c.M, 128) * c.tiles_n >= 512 && !(x6 && G == 3);
   void* pr = gemm_prof_begin(2.0 * c.M * G * c.HP * (double)c.K, st);
-  if (big) {
-    c.nblk = cdiv(c.M, 128) * c.tiles_n;
-    hipLaunchKernelGGL((level_kernel<G, 2, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);
-  } else {
-    c.nblk = cdiv(c.M, 64) * c.tiles_n;
-    hipLaunchKernelGGL((level_kernel<G, 1, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);
+  c.nblk = cdiv(c.M, big ? 128 : 64) * c.tiles_n;
+  if constexpr (!GATHER) {
+    if constexpr (G != 3) {
+      if (x6 && big) hipLaunchKernelGGL((level_x6_kernel<G, 2, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+    }
+    if (x6 && !big) hipLaunchKernelGGL((level_x6_kernel<G, 1, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
   }
+  if (!x6 && big) hipLaunchKernelGGL((level_kernel<G, 2, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);
+  if (!x6 && !big) hipLaunchKernelGGL((level_kernel<G, 1, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);
   gemm_prof_end(pr, st);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;

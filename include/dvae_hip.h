@@ -266,7 +266,7 @@ int dvae_step_part2(const dvae_step* s, void* stream, void* side_stream);
 
 /* Tuning / test knob of the forward level sweep (no counterpart in the reference): node rows
  * per level from which the gate/map step runs as ONE fused launch (GEMM + sigmoid*map
- * epilogue; -1 never, 0 always, -2 = default: 2048 beside the fp32-MFMA GEMM core, never beside the x6 core)
+ * epilogue; -1 never, 0 always, -2 = default: 2048; the fused kernels run on the arithmetic core dvae_gemm_x6 selects)
  * and whether the GRU step runs fused (hidden
  * GEMM + gates in one launch; default 0); type_share: whether the decoder serves its type-only
  * prefix rows from the per-type table when dvae_sched_types allows it (default 1).  Every
