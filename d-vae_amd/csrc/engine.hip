@@ -86,7 +86,8 @@ struct Scratch { float* gemm_ws; float* part; size_t part_floats; };
 struct EncWs {
   SweepBufs f, r;
   float *HVF, *ML, *DML, *DHVF;
-  float *HVC, *CAT, *DHVC, *DCAT;   // bidirectional chain
+  float *HVC, *DHVC;                // bidirectional chain: hv_t / dL/dhv_t, [(N+1)][B][HP]
+  float *Q, *DQ, *DA;               // W01b.hb + b01 per reverse-sweep node row and its gradient; masked copy of dL/dhv_{t+1}
   Scratch sc[2];
   size_t bytes;
 };
@@ -110,13 +111,14 @@ EncWs enc_ws(const dvae_dims& d, int R, int E, void* base) {
   if (d.bidir) {
     carve_sweep(c, w.r, 0, R, E, d.HP, pos_cols(d));
     w.HVC = c.f((size_t)(d.N + 1) * B * d.HP);
-    w.CAT = c.f((size_t)d.N * B * 2 * d.HP);
     w.DHVC = c.f((size_t)(d.N + 1) * B * d.HP);
-    w.DCAT = c.f(B * 2 * d.HP);
+    w.Q = c.f((size_t)std::max(R, 1) * d.HP);
+    w.DQ = c.f((size_t)std::max(R, 1) * d.HP);
+    w.DA = c.f((size_t)d.N * B * d.HP);
     w.HVF = w.HVC + (size_t)d.N * B * d.HP;
   } else {
     w.r = SweepBufs{};
-    w.HVC = w.CAT = w.DHVC = w.DCAT = nullptr;
+    w.HVC = w.DHVC = w.Q = w.DQ = w.DA = nullptr;
     w.HVF = c.f(B * d.HP);
   }
   carve_scratch(c, d, w.sc);
@@ -606,14 +608,14 @@ extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* 
     const Levels lr = levels_of(d, info, 1);
     SweepW wr{gru_at(P + L.gru_b, HP, d.C), P + L.gm_b};
     DVAE_TRY(sweep_fwd(d, sv.dir[1], lr, w.r, wr, x, nullptr, g));
-    // lin01 chain, applied once per reverse-sweep step (dvae_model.py:119)
+    // lin01 chain, applied once per reverse-sweep step (dvae_model.py:119): hv_{t+1} = W01.[hv_t ; hb] + b01.  The hb
+    // half does not depend on the chain: Q = W01b.hb + b01 for every reverse-sweep node row in ONE product, and a step is
+    // one launch (hv_t.W01a^T + Q's row for the graphs that still have a step t, hv_t for the others)
     DVAE_TRY(k_take_last_fwd(sv.dir[0], sizes, B, d.N, w.f.Hn, w.HVC, HP, st));
+    DVAE_TRY(g.nt(w.r.Hn, HP, P + L.W01 + HP, 2 * HP, w.Q, HP, lr.R, HP, HP, P + L.b01));
     for (int t = 0; t < d.N; ++t) {
       float* hv_t = w.HVC + (size_t)t * B * HP;
-      float* cat = w.CAT + (size_t)t * B * 2 * HP;
-      DVAE_TRY(k_chain_cat(sv.dir[1], sizes, B, d.N, t, hv_t, w.r.Hn, cat, HP, st));
-      DVAE_TRY(g.nt(cat, 2 * HP, P + L.W01, 2 * HP, hv_t + (size_t)B * HP, HP, B, HP, 2 * HP, P + L.b01));
-      DVAE_TRY(k_chain_select(sizes, B, t, hv_t, hv_t + (size_t)B * HP, HP, st));
+      DVAE_TRY(k_chain_fwd_step(sv.dir[1], sizes, B, d.N, t, hv_t, P + L.W01, 2 * HP, w.Q, hv_t + (size_t)B * HP, HP, g.prio, st));
     }
   } else {
     DVAE_TRY(k_take_last_fwd(sv.dir[0], sizes, B, d.N, w.f.Hn, w.HVF, HP, st));
@@ -668,24 +670,24 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     const Levels lr = levels_of(d, info, 1);
     SweepW wr{gru_at(P + L.gru_b, HP, d.C), P + L.gm_b};
     DVAE_TRY(k_zero(w.r.DH, (size_t)std::max(lf.R, 1) * HP * 4, st));
-    // chain backward; DHVC[t] = dL/d hv_t, DHVC[N] seeded by the heads
+    // chain backward; DHVC[t] = dL/d hv_t, DHVC[N] seeded by the heads.  One launch per step: d_t = d_next.W01a for the
+    // graphs with a step t (their d_next row is also the gradient of Q's row, DQ, and goes to DA, the copy with the
+    // finished graphs' rows zeroed that the weight gradient sums over), d_next itself for the finished ones
     DVAE_CHECK_HIP(hipMemcpyAsync(w.DHVC + (size_t)d.N * B * HP, w.DHVF, (size_t)B * HP * 4,
                                   hipMemcpyDeviceToDevice, st));
     for (int t = d.N - 1; t >= 0; --t) {
       float* d_t = w.DHVC + (size_t)t * B * HP;
-      float* d_next = d_t + (size_t)B * HP;
-      if (sizes) {
-        DVAE_CHECK_HIP(hipMemsetAsync(d_t, 0, (size_t)B * HP * 4, st));
-        DVAE_TRY(k_chain_mask(sizes, B, t, d_next, d_t, HP, st));
-      }
-      DVAE_TRY(g.nn(d_next, HP, P + L.W01, 2 * HP, w.DCAT, 2 * HP, B, 2 * HP, HP));
-      DVAE_TRY(k_chain_scatter(sv.dir[1], sizes, B, d.N, t, w.DCAT, d_t, w.r.DH, HP, st));
+      DVAE_TRY(k_chain_bwd_step(sv.dir[1], sizes, B, d.N, t, d_t + (size_t)B * HP, P + L.W01, 2 * HP, d_t, w.DQ,
+                                w.DA + (size_t)t * B * HP, HP, g.prio, st));
     }
     DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVC, w.f.DH, HP, st));
-    // dW01 over all N*B chain rows, db01
+    // dL/dhb = DQ.W01b into the reverse sweep's DH (zero so far); weight gradients on the side stream:
+    // dW01a = DA^T.hv_t over all N*B chain rows, dW01b = DQ^T.hb over the reverse-sweep rows, db01 = column sums of DQ
+    DVAE_TRY(g.nn(w.DQ, HP, P + L.W01 + HP, 2 * HP, w.r.DH, HP, lr.R, HP, HP, 1));
     DVAE_TRY(ev.edge(st, sd));
-    DVAE_TRY(gs.tn(w.DHVC + (size_t)B * HP, HP, w.CAT, 2 * HP, Gp + L.W01, 2 * HP, HP, 2 * HP, d.N * B));
-    DVAE_TRY(k_colsum(w.DHVC + (size_t)B * HP, HP, d.N * B, HP, Gp + L.b01, ssc.part, ssc.part_floats, sd));
+    DVAE_TRY(gs.tn(w.DA, HP, w.HVC, HP, Gp + L.W01, 2 * HP, HP, HP, d.N * B));
+    DVAE_TRY(gs.tn(w.DQ, HP, w.r.Hn, HP, Gp + L.W01 + HP, 2 * HP, HP, HP, lr.R));
+    DVAE_TRY(k_colsum(w.DQ, HP, lr.R, HP, Gp + L.b01, ssc.part, ssc.part_floats, sd));
     DVAE_TRY(sweep_bwd_wgrad(d, sv.dir[1], lr, w.r, wr, x,
                              WgradOut{Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b}, false, g, gs, ev));
   } else {

@@ -76,6 +76,11 @@ int k_level_gru_fwd_small(const SchedDir& S, int p0, int p1, const SweepBufs& b,
                           const GruW& w, int HP, int prio, hipStream_t st);
 int k_level_gm_fwd_small(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* Wgm, const float* posb,
                          int HP, int prio, hipStream_t st);
+// the bidirectional encoder's lin01 chain, one launch per step (level.hip; dvae_model.py:119)
+int k_chain_fwd_step(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* hv_t, const float* W01, int ldw,
+                     const float* Q, float* hv_next, int HP, int prio, hipStream_t st);
+int k_chain_bwd_step(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* d_next, const float* W01, int ldw,
+                     float* d_t, float* DQ, float* DA, int HP, int prio, hipStream_t st);
 int k_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int G, int HP,
                  int K, int accumulate, int prio, hipStream_t st);
 // node sweeps, levels >= 1: CSR gated-sum aggregation (in the A-tile loader) + hidden GEMM + GRU gates, one launch
@@ -105,13 +110,6 @@ int k_take_last_fwd(const SchedDir& S, const int* sizes, int B, int N, const flo
                     hipStream_t st);
 int k_take_last_bwd(const SchedDir& S, const int* sizes, int B, int N, const float* d_out, float* DH, int HP,
                     hipStream_t st);
-// lin01 chain step t (dvae_model.py:119): node i = n_b-1-t of the reverse sweep
-int k_chain_cat(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* hv_t,
-                const float* Hb, float* CAT, int HP, hipStream_t st);
-int k_chain_select(const int* sizes, int B, int t, const float* hv_t, float* hv_next, int HP, hipStream_t st);
-int k_chain_mask(const int* sizes, int B, int t, float* d_next, float* d_t, int HP, hipStream_t st);
-int k_chain_scatter(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* DCAT,
-                    float* d_t, float* DHb, int HP, hipStream_t st);
 
 // type-shared prefix rows (sched.h TypeShare): TYPEV [32][HP] = GRU(one-hot c, h_in = 0);
 // backward: from the per-type sums T[c] = dL/dhv(type), one gate-gradient row per type

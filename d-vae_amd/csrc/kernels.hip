@@ -621,64 +621,6 @@ __global__ void take_last_kernel(SchedDir S, const int* __restrict__ sizes, int 
   }
 }
 
-__global__ void chain_cat_kernel(SchedDir S, const int* __restrict__ sizes, int B, int N, int t,
-                                 const float* __restrict__ hv_t, const float* __restrict__ Hb,
-                                 float* __restrict__ CAT, int HP) {
-  const int HP4 = HP >> 2;
-  const long long total = (long long)B * HP4;
-  ITEM_LOOP(total) {
-    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
-    const int n = graph_size(sizes, b, N);
-    float4 a = zero4(), c = zero4();
-    if (t < n) {
-      a = ld4(hv_t + (size_t)b * HP + j);
-      c = ld4(Hb + (size_t)S.node2row[b * N + n - 1 - t] * HP + j);
-    }
-    st4(CAT + (size_t)b * 2 * HP + j, a);
-    st4(CAT + (size_t)b * 2 * HP + HP + j, c);
-  }
-}
-
-__global__ void chain_select_kernel(const int* __restrict__ sizes, int B, int t,
-                                    const float* __restrict__ hv_t, float* __restrict__ hv_next, int HP) {
-  const int HP4 = HP >> 2;
-  const long long total = (long long)B * HP4;
-  ITEM_LOOP(total) {
-    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
-    if (t >= sizes[b]) st4(hv_next + (size_t)b * HP + j, ld4(hv_t + (size_t)b * HP + j));
-  }
-}
-
-// graphs already finished at step t pass their gradient straight through
-__global__ void chain_mask_kernel(const int* __restrict__ sizes, int B, int t, float* __restrict__ d_next,
-                                  float* __restrict__ d_t, int HP) {
-  const int HP4 = HP >> 2;
-  const long long total = (long long)B * HP4;
-  ITEM_LOOP(total) {
-    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
-    if (t >= sizes[b]) {
-      st4(d_t + (size_t)b * HP + j, ld4(d_next + (size_t)b * HP + j));
-      st4(d_next + (size_t)b * HP + j, zero4());
-    }
-  }
-}
-
-__global__ void chain_scatter_kernel(SchedDir S, const int* __restrict__ sizes, int B, int N, int t,
-                                     const float* __restrict__ DCAT, float* __restrict__ d_t,
-                                     float* __restrict__ DHb, int HP) {
-  const int HP4 = HP >> 2;
-  const long long total = (long long)B * HP4;
-  ITEM_LOOP(total) {
-    const int b = (int)(it / HP4), j = (int)(it % HP4) * 4;
-    const int n = graph_size(sizes, b, N);
-    if (t < n) {
-      st4(d_t + (size_t)b * HP + j, ld4(DCAT + (size_t)b * 2 * HP + j));
-      float* dst = DHb + (size_t)S.node2row[b * N + n - 1 - t] * HP + j;
-      st4(dst, add4(ld4(dst), ld4(DCAT + (size_t)b * 2 * HP + HP + j)));
-    }
-  }
-}
-
 // graph_state of node i: h0 (i=0) | state of node i-1 (None, :257) | sum of states < i (bn, :251-255)
 __global__ void graph_state_fwd_kernel(SchedDir S, int R, int N, int mod, const float* __restrict__ Hn,
                                        const float* __restrict__ h0, float* __restrict__ GS, int HP) {
@@ -1448,38 +1390,6 @@ int k_take_last_bwd(const SchedDir& S, const int* sizes, int B, int N, const flo
                     hipStream_t st) {
   hipLaunchKernelGGL(take_last_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, S, sizes, B, N,
                      d_out, DH, HP, 1);
-  DVAE_LAUNCH_CHECK();
-  return DVAE_OK;
-}
-
-int k_chain_cat(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* hv_t,
-                const float* Hb, float* CAT, int HP, hipStream_t st) {
-  hipLaunchKernelGGL(chain_cat_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, Srev, sizes, B, N, t,
-                     hv_t, Hb, CAT, HP);
-  DVAE_LAUNCH_CHECK();
-  return DVAE_OK;
-}
-
-int k_chain_select(const int* sizes, int B, int t, const float* hv_t, float* hv_next, int HP, hipStream_t st) {
-  if (!sizes) return DVAE_OK;
-  hipLaunchKernelGGL(chain_select_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, sizes, B, t, hv_t,
-                     hv_next, HP);
-  DVAE_LAUNCH_CHECK();
-  return DVAE_OK;
-}
-
-int k_chain_mask(const int* sizes, int B, int t, float* d_next, float* d_t, int HP, hipStream_t st) {
-  if (!sizes) return DVAE_OK;
-  hipLaunchKernelGGL(chain_mask_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, sizes, B, t, d_next,
-                     d_t, HP);
-  DVAE_LAUNCH_CHECK();
-  return DVAE_OK;
-}
-
-int k_chain_scatter(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* DCAT,
-                    float* d_t, float* DHb, int HP, hipStream_t st) {
-  hipLaunchKernelGGL(chain_scatter_kernel, grid_for((long long)B * (HP / 4)), dim3(256), 0, st, Srev, sizes, B, N,
-                     t, DCAT, d_t, DHb, HP);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }

@@ -419,6 +419,44 @@ __device__ __forceinline__ void epilogue_plain(const PlainEpi& e, int HP, const 
   }
 }
 
+// lin01 chain of the bidirectional encoder (dvae_model.py:119): hv_{t+1} = W01a.hv_t + (W01b.hb + b01) for the graphs that
+// still have a reverse-sweep step t, hv_t for the others.  Q holds W01b.hb + b01 per reverse-sweep node row (one GEMM).
+struct ChainFwdEpi {
+  const int* sizes; int N, t; const int* node2row;
+  const float* hv_t; const float* Q; float* hv_next;
+};
+struct ChainFwdRow { int b; };
+__device__ __forceinline__ ChainFwdRow row_meta(const ChainFwdEpi&, int, int m) { return ChainFwdRow{m}; }
+// backward of one chain step: d_t = d_next.W01a for the active graphs (their d_next row also goes to DQ, the gradient of
+// Q's row, and to DA, the masked copy the weight gradient sums over), d_next for the finished ones
+struct ChainBwdEpi {
+  const int* sizes; int N, t; const int* node2row;
+  const float* d_next; float* d_t; float* DQ; float* DA;
+};
+struct ChainBwdRow { int b; int qrow; };         // qrow < 0: finished
+__device__ __forceinline__ ChainBwdRow row_meta(const ChainBwdEpi& e, int, int m) {
+  const int n = e.sizes ? e.sizes[m] : e.N;
+  return ChainBwdRow{m, e.t < n ? e.node2row[m * e.N + n - 1 - e.t] : -1};
+}
+
+template <int G> __device__ __forceinline__ void small_epilogue(const ChainFwdEpi& e, int HP, const ChainFwdRow& rw, int col, const float4* v) {
+  const int n = e.sizes ? e.sizes[rw.b] : e.N;
+  float4 x;
+  if (e.t < n) x = add4(v[0], ld4(e.Q + (size_t)e.node2row[rw.b * e.N + n - 1 - e.t] * HP + col));
+  else x = ld4(e.hv_t + (size_t)rw.b * HP + col);
+  st4(e.hv_next + (size_t)rw.b * HP + col, x);
+}
+template <int G> __device__ __forceinline__ void small_epilogue(const ChainBwdEpi& e, int HP, const ChainBwdRow& rw, int col, const float4* v) {
+  const float4 dn = ld4(e.d_next + (size_t)rw.b * HP + col);
+  if (rw.qrow >= 0) {
+    st4(e.d_t + (size_t)rw.b * HP + col, v[0]);
+    st4(e.DQ + (size_t)rw.qrow * HP + col, dn);
+    st4(e.DA + (size_t)rw.b * HP + col, dn);
+  } else {
+    st4(e.d_t + (size_t)rw.b * HP + col, dn);
+    st4(e.DA + (size_t)rw.b * HP + col, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
 template <int G> __device__ __forceinline__ void small_epilogue(const GruEpi& e, int HP, const GruRow& rw, int col, const float4* v) { epilogue(e, HP, rw, col, v); }
 template <int G> __device__ __forceinline__ void small_epilogue(const GmEpi& e, int HP, const GmRow& rw, int col, const float4* v) { epilogue(e, HP, rw, col, v); }
 template <int G> __device__ __forceinline__ void small_epilogue(const PlainEpi& e, int HP, const PlainRow& rw, int col, const float4* v) { epilogue_plain<G>(e, HP, rw, col, v); }
@@ -589,6 +627,28 @@ int k_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor,
   if (G == 1) return launch_small<1, PlainEpi, 0>(c, e, st);
   if (G == 2) return launch_small<2, PlainEpi, 0>(c, e, st);
   return launch_small<3, PlainEpi, 0>(c, e, st);
+}
+
+// one step of the lin01 chain, forward: hv_next[b] = hv_t[b].W01a^T + Q[row(b, t)] (graphs with a step t) | hv_t[b]
+int k_chain_fwd_step(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* hv_t, const float* W01, int ldw,
+                     const float* Q, float* hv_next, int HP, int prio, hipStream_t st) {
+  if (B <= 0) return DVAE_OK;
+  DVAE_REQUIRE(HP % 32 == 0, "chain_fwd_step: HP must be a multiple of 32");
+  LevelCore c{};
+  c.A = hv_t; c.lda = HP; c.M = B; c.W = W01; c.ldw = ldw; c.K = HP; c.HP = HP; c.prio = prio;
+  ChainFwdEpi e{sizes, N, t, Srev.node2row, hv_t, Q, hv_next};
+  return launch_small<1, ChainFwdEpi, 0>(c, e, st);
+}
+
+// backward: d_t[b] = d_next[b].W01a (graphs with a step t; DQ[row(b, t)] = DA[b] = d_next[b]) | d_next[b] (DA[b] = 0)
+int k_chain_bwd_step(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* d_next, const float* W01, int ldw,
+                     float* d_t, float* DQ, float* DA, int HP, int prio, hipStream_t st) {
+  if (B <= 0) return DVAE_OK;
+  DVAE_REQUIRE(HP % 32 == 0, "chain_bwd_step: HP must be a multiple of 32");
+  LevelCore c{};
+  c.A = d_next; c.lda = HP; c.M = B; c.W = W01; c.ldw = ldw; c.K = HP; c.HP = HP; c.prio = prio;
+  ChainBwdEpi e{sizes, N, t, Srev.node2row, d_next, d_t, DQ, DA};
+  return launch_small<1, ChainBwdEpi, 1>(c, e, st);
 }
 
 int k_level_gru_fwd_small(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
