@@ -438,33 +438,42 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   for (int L = lv.nlev - 1; L >= 0; --L) {
     const int ns = lv.ls[L], ne = lv.ls[L + 1];
     GemmPartials gparts{nullptr, 1, 0};   // gate/map input gradient of this level, when left as split-K slabs
+    bool gru_done = false;                // this level's GRUCell backward ran as the epilogue of that product
     if (L + 1 < lv.nlev) {
       if (pg) {
         // dL/dGM[u] = (direct gradients of the rows that hold u) + (their dgh, summed).Whh: the hidden
         // product's input gradient once per node instead of once per prefix row
         DVAE_TRY(k_dgm_gather(S, ns, ne, b, HP, st));
-        GemmPartials parts{nullptr, 1, 0};   // a mid-sized level's split-K slabs are added by the consumer
-        if (ne - ns <= small_rows)
-          DVAE_TRY(small_nn(b.PG + (size_t)ns * 3 * HP, 3 * HP, w.gru.Whh, b.DGM + (size_t)ns * HP, ne - ns));
-        else
+        if (ne - ns <= small_rows) {
+          // hidden part of dL/dGM and the gate/map backward in one launch (level.hip small_kernel)
+          DVAE_TRY(k_level_gm_bwd_small(ns, ne, b, w.gru.Whh, HP, g.prio, st));
+        } else {
+          GemmPartials parts{nullptr, 1, 0};   // a mid-sized level's split-K slabs are added by the consumer
           DVAE_TRY(g.nn(b.PG + (size_t)ns * 3 * HP, 3 * HP, w.gru.Whh, HP, b.DGM + (size_t)ns * HP, HP, ne - ns, HP,
                         3 * HP, 1, nullptr, fold_partials_bwd ? &parts : nullptr));
-        DVAE_TRY(k_gm_bwd_apply(ns, ne, b, HP, st, &parts));
+          DVAE_TRY(k_gm_bwd_apply(ns, ne, b, HP, st, &parts));
+        }
       } else {
         DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
       }
-      if (ne - ns <= small_rows)
+      if (ne - ns <= small_rows && !b.prefix) {
+        // node sweeps: the gate/map input gradient lands on the rows whose GRU step comes next -- product and
+        // GRUCell backward in one launch (level.hip small_kernel)
+        DVAE_TRY(k_level_gru_bwd_small(ns, ne, b, w.gm, HP, g.prio, st));
+        gru_done = true;
+      } else if (ne - ns <= small_rows) {
         DVAE_TRY(small_nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, dtarget + (size_t)ns * HP, ne - ns));
-      else
+      } else {
         DVAE_TRY(g.nn(b.GMP + (size_t)ns * 2 * HP, 2 * HP, w.gm, HP, dtarget + (size_t)ns * HP, HP, ne - ns, HP,
                       2 * HP, 1, nullptr, fold_partials_bwd ? &gparts : nullptr));
+      }
     }
     if (L == 0) {
-      DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st, &gparts, ns));
+      if (!gru_done) DVAE_TRY(k_gru_bwd(S, ns, ne, b, HP, st, &gparts, ns));
       if (seeded) DVAE_TRY(dagg_gemm(ns, ne));      // only node 0's h_in = h0 needs it
     } else {
       const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
-      DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st, &gparts, ns));
+      if (!gru_done) DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st, &gparts, ns));
       if (!pg) DVAE_TRY(dagg_gemm(p0, p1));
     }
     if (after_level) DVAE_TRY(after_level(L));   // levels >= L are final from here on

@@ -81,6 +81,8 @@ int k_chain_fwd_step(const SchedDir& Srev, const int* sizes, int B, int N, int t
                      const float* Q, float* hv_next, int HP, int prio, hipStream_t st);
 int k_chain_bwd_step(const SchedDir& Srev, const int* sizes, int B, int N, int t, const float* d_next, const float* W01, int ldw,
                      float* d_t, float* DQ, float* DA, int HP, int prio, hipStream_t st);
+int k_level_gm_bwd_small(int ns, int ne, const SweepBufs& b, const float* Whh, int HP, int prio, hipStream_t st);
+int k_level_gru_bwd_small(int ns, int ne, const SweepBufs& b, const float* Wgm, int HP, int prio, hipStream_t st);
 int k_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor, float* C, int ldc, int M, int G, int HP,
                  int K, int accumulate, int prio, hipStream_t st);
 // node sweeps, levels >= 1: CSR gated-sum aggregation (in the A-tile loader) + hidden GEMM + GRU gates, one launch

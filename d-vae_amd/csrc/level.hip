@@ -457,6 +457,45 @@ template <int G> __device__ __forceinline__ void small_epilogue(const ChainBwdEp
     st4(e.DA + (size_t)rw.b * HP + col, make_float4(0.f, 0.f, 0.f, 0.f));
   }
 }
+// prefix sweeps, backward: dL/dGM[u] = (direct part, gathered into DGM) + dPG[u].Whh, then the gate/map backward
+// (kernels.hip gm_bwd_apply_kernel's formulas) on the product's own tile: GMP (g, m) -> (dg_pre, dm)
+struct GmBwdEpi { int r_base; const float* DGM; float* GMP; };
+struct GmBwdRow { int r; };
+__device__ __forceinline__ GmBwdRow row_meta(const GmBwdEpi& e, int, int m) { return GmBwdRow{e.r_base + m}; }
+template <int G> __device__ __forceinline__ void small_epilogue(const GmBwdEpi& e, int HP, const GmBwdRow& rw, int col, const float4* v) {
+  const float4 d = add4(v[0], ld4(e.DGM + (size_t)rw.r * HP + col));
+  float* gp = e.GMP + (size_t)rw.r * 2 * HP;
+  const float4 g = ld4(gp + col), m = ld4(gp + HP + col);
+  st4(gp + col, make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
+                            d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w)));
+  st4(gp + HP + col, make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w));
+}
+// node sweeps, backward: dL/dh of node rows = what DH holds + dGMP.[Wg;Wm] (this product), then the GRUCell backward
+// (kernels.hip gru_bwd_kernel's formulas) on the product's own tile
+struct GruBwdEpi { int r_base; float* GH; float* GHN; const float* AGG; float* DH; };
+struct GruBwdRow { int p; };
+__device__ __forceinline__ GruBwdRow row_meta(const GruBwdEpi& e, int, int m) { return GruBwdRow{e.r_base + m}; }
+template <int G> __device__ __forceinline__ void small_epilogue(const GruBwdEpi& e, int HP, const GruBwdRow& rw, int col, const float4* v) {
+  const float4 dh = add4(v[0], ld4(e.DH + (size_t)rw.p * HP + col));
+  float* gh = e.GH + (size_t)rw.p * 3 * HP;
+  const float4 rr = ld4(gh + col), zz = ld4(gh + HP + col), nn = ld4(gh + 2 * HP + col);
+  const float4 ghn = ld4(e.GHN + (size_t)rw.p * HP + col);
+  const float4 a = ld4(e.AGG + (size_t)rw.p * HP + col);
+  float4 drp, dzp, dnp, dnr, da;
+#define BWD_LANE(f)                                              \
+  dnp.f = dh.f * (1.f - zz.f) * (1.f - nn.f * nn.f);              \
+  dzp.f = dh.f * (a.f - nn.f) * zz.f * (1.f - zz.f);              \
+  drp.f = dnp.f * ghn.f * rr.f * (1.f - rr.f);                    \
+  dnr.f = dnp.f * rr.f;                                           \
+  da.f = dh.f * zz.f;
+  BWD_LANE(x) BWD_LANE(y) BWD_LANE(z) BWD_LANE(w)
+#undef BWD_LANE
+  st4(gh + col, drp);
+  st4(gh + HP + col, dzp);
+  st4(gh + 2 * HP + col, dnr);
+  st4(e.GHN + (size_t)rw.p * HP + col, dnp);
+  st4(e.DH + (size_t)rw.p * HP + col, da);
+}
 template <int G> __device__ __forceinline__ void small_epilogue(const GruEpi& e, int HP, const GruRow& rw, int col, const float4* v) { epilogue(e, HP, rw, col, v); }
 template <int G> __device__ __forceinline__ void small_epilogue(const GmEpi& e, int HP, const GmRow& rw, int col, const float4* v) { epilogue(e, HP, rw, col, v); }
 template <int G> __device__ __forceinline__ void small_epilogue(const PlainEpi& e, int HP, const PlainRow& rw, int col, const float4* v) { epilogue_plain<G>(e, HP, rw, col, v); }
@@ -649,6 +688,28 @@ int k_chain_bwd_step(const SchedDir& Srev, const int* sizes, int B, int N, int t
   c.A = d_next; c.lda = HP; c.M = B; c.W = W01; c.ldw = ldw; c.K = HP; c.HP = HP; c.prio = prio;
   ChainBwdEpi e{sizes, N, t, Srev.node2row, d_next, d_t, DQ, DA};
   return launch_small<1, ChainBwdEpi, 1>(c, e, st);
+}
+
+// prefix sweeps, backward, node rows [ns,ne): hidden part of dL/dGM (dPG.Whh) + gate/map backward, one launch
+int k_level_gm_bwd_small(int ns, int ne, const SweepBufs& b, const float* Whh, int HP, int prio, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  DVAE_REQUIRE(HP % 32 == 0, "level_gm_bwd_small: HP must be a multiple of 32");
+  LevelCore c{};
+  c.A = b.PG + (size_t)ns * 3 * HP; c.lda = 3 * HP; c.M = ne - ns;
+  c.W = Whh; c.ldw = HP; c.K = 3 * HP; c.HP = HP; c.prio = prio;
+  GmBwdEpi e{ns, b.DGM, b.GMP};
+  return launch_small<1, GmBwdEpi, 1>(c, e, st);
+}
+
+// node sweeps, backward, node rows [ns,ne): gate/map input gradient (dGMP.[Wg;Wm]) into dL/dh + GRUCell backward, one launch
+int k_level_gru_bwd_small(int ns, int ne, const SweepBufs& b, const float* Wgm, int HP, int prio, hipStream_t st) {
+  if (ne <= ns) return DVAE_OK;
+  DVAE_REQUIRE(HP % 32 == 0 && !b.prefix, "level_gru_bwd_small: node sweeps, HP a multiple of 32");
+  LevelCore c{};
+  c.A = b.GMP + (size_t)ns * 2 * HP; c.lda = 2 * HP; c.M = ne - ns;
+  c.W = Wgm; c.ldw = HP; c.K = 2 * HP; c.HP = HP; c.prio = prio;
+  GruBwdEpi e{ns, b.GH, b.GHN, b.AGG, b.DH};
+  return launch_small<1, GruBwdEpi, 1>(c, e, st);
 }
 
 int k_level_gru_fwd_small(const SchedDir& S, int p0, int p1, const SweepBufs& b, const float* x, int N, int C,
