@@ -3,6 +3,8 @@
 // weight-gradient column reductions, the add_edge pair scorer and glue copies.
 // No atomics anywhere: every reduction is "partials in a fixed order, then a
 // sum", so results are bitwise reproducible run to run.
+#include <mutex>
+
 #include "kernels.h"
 
 #include <algorithm>
@@ -28,10 +30,21 @@ __device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
   return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
 }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// sum over the 64 lanes of a wave, the same value in every lane.  DPP moves inside the VALU (quad permutes, row
+// rotations, row broadcasts; the total lands in lane 63) instead of six ds_bpermute round trips through the LDS
+// crossbar: the pair scorers reduce once per scored pair.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = dpp_add<0xb1, 0xf>(v);    // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);    // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);   // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);   // row_ror:8      every lane of a row of 16 holds its row's sum
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast:15   rows 1 and 3 add the sum of the row before
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast:31   rows 2 and 3 add lane 31: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---------------------------------------------------------------------------
@@ -811,6 +824,93 @@ __global__ __launch_bounds__(256) void pair_fwd_kernel(SchedView sv, TypeShare t
   }
 }
 
+// The pair scorer for LARGER graphs (N > 16): pair_fwd_kernel reads an 8-12 KB Bq row per PAIR, and a 64-node graph's
+// Bq rows (512 KB) fit no L1 and, with ~100 graphs in flight per XCD, no L2 either (config 3: 53 GB per step, the
+// algorithmic 13).  Here a 1024-thread workgroup takes one graph and walks the add_edge width in slices of 512 columns:
+// the slice of the Bq rows of a window of CW candidate nodes is staged in LDS (CW x 2 KB), every wave takes node rows of
+// the graph and scores their pairs against it (A's slice of a prefix row is read once per slice, Bq comes from LDS), and
+// the partial logits of the slices meet in an LDS table (row i, candidate j: always the same wave, the same lane -- no
+// atomics, a fixed order), written out once per window.
+constexpr int PF_SL = 512;   // columns per slice
+__global__ __launch_bounds__(1024) void pair_fwd_slice_kernel(SchedView sv, TypeShare ts, int R, int EHP, int CW,
+                                                              const int* __restrict__ sizes,
+                                                              const float* __restrict__ A,
+                                                              const float* __restrict__ Bq,
+                                                              const float* __restrict__ Cq,
+                                                              const float* __restrict__ w2,
+                                                              const float* __restrict__ b2,
+                                                              float* __restrict__ edge_logits) {
+  extern __shared__ __attribute__((aligned(16))) float pf_lds[];
+  float* bql = pf_lds;                         // [CW][PF_SL]
+  float* lg = pf_lds + (size_t)CW * PF_SL;     // [N][CW] partial logits of (row i, candidate jb + jj)
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int ns = EHP / PF_SL;
+  const float bias2 = b2[0];
+  for (int b = blockIdx.x; b < sv.B; b += gridDim.x) {
+    const int n = graph_size(sizes, b, N);
+    for (int jb = 0; jb + 1 < n; jb += CW) {
+      const int cw = min(CW, n - jb);          // candidates jb .. jb + cw - 1 (the last node is never one: harmless)
+      for (int sl = 0; sl < ns; ++sl) {
+        const int c0 = sl * PF_SL;
+        __syncthreads();                       // the previous slice / window is done with bql (and lg, when sl == 0)
+        for (int q = threadIdx.x; q < cw * (PF_SL / 4); q += blockDim.x) {
+          const int jj = q / (PF_SL / 4), cq = (q % (PF_SL / 4)) * 4;
+          st4(bql + jj * PF_SL + cq, ld4(Bq + (size_t)S.node2row[b * N + jb + jj] * EHP + c0 + cq));
+        }
+        __syncthreads();
+        const float4 w0 = ld4(w2 + c0 + lane * 4), w1 = ld4(w2 + c0 + 256 + lane * 4);
+        const float4 cc0 = Cq ? ld4(Cq + (size_t)b * EHP + c0 + lane * 4) : zero4();
+        const float4 cc1 = Cq ? ld4(Cq + (size_t)b * EHP + c0 + 256 + lane * 4) : zero4();
+        for (int i = jb + 1 + wave; i < n; i += nwaves) {
+          const int r = S.node2row[b * N + i];
+          const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+          const int jtop = min(jb + cw, i) - 1;   // the highest candidate of this window that node i is paired with
+          int t = 0;
+          while (t < deg && S.row_node[S.csr_idx[p + t]] > jtop) ++t;
+          int next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
+          int cur = -1;
+          float4 a0 = zero4(), a1 = zero4();
+          for (int j = jtop; j >= jb; --j) {
+            while (t < deg && next_pred > j) {
+              ++t;
+              next_pred = t < deg ? S.row_node[S.csr_idx[p + t]] : -1;
+            }
+            if (t != cur) {
+              const float* ar = a_row(sv, ts, A, EHP, R, r, t) + c0;
+              a0 = add4(ld4(ar + lane * 4), cc0);
+              a1 = add4(ld4(ar + 256 + lane * 4), cc1);
+              cur = t;
+            }
+            const float* bj = bql + (j - jb) * PF_SL;
+            const float4 q0 = add4(a0, ld4(bj + lane * 4)), q1 = add4(a1, ld4(bj + 256 + lane * 4));
+            float sum = 0.f;
+            sum = fmaf(w0.x, fmaxf(q0.x, 0.f), sum);
+            sum = fmaf(w0.y, fmaxf(q0.y, 0.f), sum);
+            sum = fmaf(w0.z, fmaxf(q0.z, 0.f), sum);
+            sum = fmaf(w0.w, fmaxf(q0.w, 0.f), sum);
+            sum = fmaf(w1.x, fmaxf(q1.x, 0.f), sum);
+            sum = fmaf(w1.y, fmaxf(q1.y, 0.f), sum);
+            sum = fmaf(w1.z, fmaxf(q1.z, 0.f), sum);
+            sum = fmaf(w1.w, fmaxf(q1.w, 0.f), sum);
+            sum = wave_sum(sum);
+            if (lane == 0) {
+              float* dst = lg + i * CW + (j - jb);
+              *dst = sl == 0 ? sum : *dst + sum;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (int q = threadIdx.x; q < (n - jb - 1) * cw; q += blockDim.x) {
+        const int i = jb + 1 + q / cw, jj = q % cw;
+        if (jb + jj < i) edge_logits[((size_t)b * N + i) * N + jb + jj] = lg[i * CW + jj] + bias2;
+      }
+    }
+  }
+}
+
 // the same with one wave per node row in row order (rows of one level side by side)
 template <int VPL>
 __global__ __launch_bounds__(256) void pair_fwd_rows_kernel(SchedView sv, TypeShare ts, int R,
@@ -1418,6 +1518,25 @@ int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const int* sizes
   if (R <= 0) return DVAE_OK;
   static const bool by_rows = getenv("DVAE_PAIR_FWD_ROWS") != nullptr;   // lab: the row-order mapping
   static const int cap = getenv("DVAE_PAIR_FWD_GRID") ? atoi(getenv("DVAE_PAIR_FWD_GRID")) : 4096;   // lab
+  // graphs of more than 16 nodes: Bq windows in LDS, the add_edge width in slices (DVAE_NO_PAIR_FWD_SLICE=1: A-B tests)
+  static const bool no_slice = getenv("DVAE_NO_PAIR_FWD_SLICE") != nullptr;
+  if (!by_rows && !no_slice && sv.N > 16 && sv.N <= 128 && EHP % PF_SL == 0) {
+    const int CW = sv.N <= 64 ? sv.N : 56;
+    const size_t lds_bytes = ((size_t)CW * PF_SL + (size_t)sv.N * CW) * sizeof(float);   // <= 143 KB
+    static std::once_flag big_lds[16];   // per device: more than 64 KB of LDS is opt-in
+    int dev = 0;
+    DVAE_CHECK_HIP(hipGetDevice(&dev));
+    hipError_t attr_err = hipSuccess;
+    std::call_once(big_lds[dev & 15], [&] {
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_fwd_slice_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    DVAE_CHECK_HIP(attr_err);
+    hipLaunchKernelGGL(pair_fwd_slice_kernel, dim3(std::min(sv.B, 1024)), dim3(1024), lds_bytes, st, sv, ts, R, EHP, CW,
+                       sizes, A, Bq, Cq, w2, b2, edge_logits);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+  }
   if (by_rows) {
     const int grid = std::min(cdiv(R, 4), cap);
     VPL_DISPATCH(EHP, hipLaunchKernelGGL((pair_fwd_rows_kernel<V>), dim3(grid), dim3(256), 0, st, sv, ts, R, A, Bq, Cq,
