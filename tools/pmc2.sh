@@ -7,6 +7,6 @@ for e in $envs; do export "$e"; done
 for pass in "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   name=${pass%%:*}; ctr=${pass#*:}
   rm -rf gpurun_out/pmc_${tag}_$name
-  timeout -s KILL 300 rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 bench.py --no-cpu-baseline --no-profile "$@" > gpurun_out/pmc_${tag}_$name.log 2>&1 || { echo "pass $name failed"; tail -3 gpurun_out/pmc_${tag}_$name.log; exit 1; }
+  timeout -s KILL 300 rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 bench.py --no-cpu-baseline --no-profile --no-core-ab "$@" > gpurun_out/pmc_${tag}_$name.log 2>&1 || { echo "pass $name failed"; tail -3 gpurun_out/pmc_${tag}_$name.log; exit 1; }
   echo "$tag pass $name ok"
 done
