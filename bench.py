@@ -184,6 +184,24 @@ def cpu_baseline(cfg_name, seconds_budget=20.0):
                       % (n, note, dt * 1e3)}
 
 
+def kept_pmc_traffic(cfg_name):
+    """HBM bytes measured by the kept rocprofv3 counter passes (tools/pmc.sh; profiles/r03_pmc_traffic.json is written
+    by tools/pmc_traffic.py from the same pass whose summary is profiles/r03_pmc_summary.txt): the GEMM's bytes per
+    launch and the per-step bytes of the HBM-bound kernel families.  None when the file has no entry for the config."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    e = d.get(cfg_name)
+    if not e:
+        return None
+    e = dict(e)
+    e["source"] = "profiles/r03_pmc_traffic.json (" + d.get("_how", "rocprofv3 --pmc, separate passes") + ")"
+    return e
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -370,9 +388,11 @@ def main():
             lib.dvae_gemm_profile(0)
     barrier()
     dt = time.perf_counter() - t0
-    gemm = None
+    gemm = hbm = None
     if prof:
         buf = (ctypes.c_double * 12)()
+        _lib.check(lib.dvae_hbm_profile_read(ctypes.cast(buf, ctypes.c_void_p)))    # before the GEMM read, which clears the log
+        hbm = list(buf)
         _lib.check(lib.dvae_gemm_profile_read(ctypes.cast(buf, ctypes.c_void_p)))
         gemm = list(buf)
     # N = 1: the same step on the OTHER arithmetic core of the GEMM (v_mfma_f32_32x32x2_f32 instead of the default
@@ -504,6 +524,32 @@ def main():
                         "executed_tflops counts the FLOPs the launches really did" % PROF_EVERY,
                 "algorithmic_gflop_per_dag": per_dag / 1e9,
             }
+            # HBM bytes of the dominant kernel from the kept counter pass (rocprofv3 --pmc, separate passes, FETCH_SIZE
+            # doubled per MI355X_MICROARCH.md's gfx950 note + WRITE_SIZE), per launch like `achieved`
+            traffic = kept_pmc_traffic(args.config)
+            if traffic is not None:
+                res["roofline"]["traffic"] = traffic["gemm_bytes_per_launch"]
+                res["roofline"]["traffic_source"] = traffic["source"]
+            if hbm is not None and cfg["kind"] == "train":
+                # the HBM-bound kernels north_star names, bracketed by the same sampled HIP events on their own stream:
+                # achieved = ALGORITHMIC bytes (aggregation 4H(E + 2N) per sweep, pair scoring 16H(E + 2N)
+                # + 4 per pair, backward 2 x) / measured launch time, against the 8 TB/s HBM peak.  They share the CUs with
+                # the side stream's GEMMs while they run.
+                names = ("pair scorer forward (pair_fwd*)", "pair scorer backward (pair_bwd*)",
+                         "gated-sum aggregation forward (agg_fwd, prefix_gru_fwd)",
+                         "aggregation backward: transpose gather (dgm_bwd, dgm_gather)")
+                rows = []
+                for k, name in enumerate(names):
+                    n_l, ms_k, by = hbm[3 * k:3 * k + 3]
+                    if n_l <= 0 or ms_k <= 0:
+                        continue
+                    tbps = by / (ms_k * 1e-3) / 1e12
+                    row = {"kernel": name, "launches_per_step": n_l / prof_steps, "algorithmic_GB_per_step": by / prof_steps / 1e9,
+                           "ms_per_step": ms_k / prof_steps, "TBps": tbps, "frac_of_8": tbps / PEAK_HBM_TBS}
+                    if traffic is not None and traffic.get("hbm", {}).get(str(k)):
+                        row["traffic_GB_per_step"] = traffic["hbm"][str(k)]
+                    rows.append(row)
+                res["roofline"]["hbm"] = rows
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(res), flush=True)

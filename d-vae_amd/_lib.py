@@ -83,9 +83,11 @@ SIGNATURES = {
     "dvae_gemm_dbg": (c_int, [c_int]),
     "dvae_level_tune": (c_int, [c_int, c_int, c_int]),
     "dvae_small_rows_tune": (c_int, [c_int]),
+    "dvae_pair_path": (c_int, [c_int, c_int]),
     "dvae_wgrad_split_tune": (c_int, [ctypes.c_double, c_int]),
     "dvae_gemm_profile": (c_int, [c_int]),
     "dvae_gemm_profile_read": (c_int, [c_void_p]),
+    "dvae_hbm_profile_read": (c_int, [c_void_p]),
     "dvae_sched_bytes": (c_size_t, [c_int, c_int]),
     "dvae_sched_build": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dvae_sched_types": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -81,3 +81,16 @@ int gemm_x6_enabled();
 // bench.py's per-launch timing hooks (gemm.hip); begin returns NULL when profiling is off
 void* gemm_prof_begin(double flops, hipStream_t st);
 void gemm_prof_end(void* h, hipStream_t st);
+// the same log for the HBM-bound kernels (dvae_hbm_profile_read): tag 4 pair scorer forward, 5 pair scorer backward,
+// 6 aggregation forward (agg_fwd, prefix_gru_fwd), 7 aggregation backward (dgm_bwd, dgm_gather); bytes = the launch's
+// ALGORITHMIC bytes.  Ends with gemm_prof_end.
+void* kernel_prof_begin(int tag, double bytes, hipStream_t st);
+struct KernelProf {
+  void* h; hipStream_t st;
+  KernelProf(int tag, double bytes, hipStream_t s) : h(kernel_prof_begin(tag, bytes, s)), st(s) {}
+  ~KernelProf() { gemm_prof_end(h, st); }
+  KernelProf(const KernelProf&) = delete;
+};
+
+// loss.hip: resolve dvae_elbo_static's per-device array address on the current device (set-up time)
+int elbo_static_warm();

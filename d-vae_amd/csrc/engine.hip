@@ -233,12 +233,18 @@ struct G {
 };
 
 struct Levels {
-  int R, E, nlev;
+  int R, E, nlev, dir;
   const int* ls;   // node-row level starts [nlev+1]
   const int* es;   // edge-space level starts (forward only)
   const int* as;   // the same in scored edge rows (SchedView::a_rows)
   int N;
   // scored edge rows before edge-space position e, which must be a level start
+  // predecessor links of level L's nodes (exact in the forward direction, pro rata in the reverse one, whose
+  // edge-space starts the schedule summary does not carry): bench.py's byte counts only
+  double level_edges(int L) const {
+    if (dir == 0) return es[L + 1] - es[L];
+    return R > 0 ? (double)E * (ls[L + 1] - ls[L]) / R : 0.0;
+  }
   int scored_before(int e) const {
     for (int L = 0; L <= N; ++L)
       if (es[L] == e) return as[L];
@@ -248,7 +254,7 @@ struct Levels {
 
 Levels levels_of(const dvae_dims& d, const int* info, int dir) {
   Levels l;
-  l.R = info[1]; l.E = info[2]; l.nlev = info[3 + dir];
+  l.R = info[1]; l.E = info[2]; l.nlev = info[3 + dir]; l.dir = dir;
   l.ls = info + 8 + dir * (d.N + 1);
   l.es = info + 8 + 2 * (d.N + 1);
   l.as = info + 8 + 3 * (d.N + 1);
@@ -296,6 +302,14 @@ bool node_hidden(const dvae_dims& d, const SweepBufs& b) {
   return g_level_cfg.node_hidden && b.prefix && d.mod == 0 && g_level_cfg.fused_gru != 1;
 }
 
+// SURVEY.md 8(d), pair scoring forward: every A row (E + N prefix rows) and every Bq row (N) read once, 16 H bytes each
+// (24 H in bn mode, whose add_edge is 6H wide), one logit written per pair; backward = 2 x.  Pairs counted as for
+// equal-size graphs (R / B nodes each), a lower bound on ragged batches.
+double pair_bytes(const dvae_dims& d, const Levels& lv) {
+  const double n = d.B > 0 ? (double)lv.R / d.B : 0.0;
+  return 4.0 * d.EH * (lv.E + 2.0 * lv.R) + 4.0 * lv.R * (n - 1.0) / 2.0;
+}
+
 struct SweepW {
   GruW gru; const float* gm;   // gm: Wgm|posb (None) or WgmT|bgm (bn)
 };
@@ -336,7 +350,10 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
   if (d.mod == 1) {
     // gate/map depends on node types only: no inter-node dependency, one "level"
     DVAE_TRY(k_gm_bn_fwd(S, R, b, x, d.N, d.C, w.gm, w.gm + (size_t)d.C * 2 * HP, HP, st));
-    DVAE_TRY(k_agg_fwd(S, 0, R, b, h0, HP, st));
+    {
+      KernelProf kp(6, 4.0 * d.H * (lv.E + 2.0 * R), st);
+      DVAE_TRY(k_agg_fwd(S, 0, R, b, h0, HP, st));
+    }
     if (!b.prefix) {
       DVAE_TRY(gru_rows(0, R));
     } else {
@@ -362,6 +379,7 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       // aggregation + hidden GEMM + GRU gates of this level's node rows in one launch
       DVAE_TRY(k_level_agg_gru_fwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, g.prio, st));
     } else if (!(pg && L > 0 && !split_pg)) {
+      KernelProf kp(6, 4.0 * d.H * (lv.level_edges(L) + 2.0 * (ne - ns)), st);
       DVAE_TRY(k_agg_fwd(S, ns, ne, b, h0, HP, st, pg ? 1 : 0));
     }
     if (gather_gru && L > 0) {
@@ -371,7 +389,10 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       else DVAE_TRY(k_gru_fwd(S, ns, ne, 1, b, x, d.N, d.C, w.gru, HP, st));
     } else {
       if (b.prefix) { p0 = R + lv.es[L]; p1 = R + lv.es[L + 1]; }
-      if (pg && !split_pg) DVAE_TRY(k_prefix_gru_fwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, st));   // aggregation + gates
+      if (pg && !split_pg) {                                                                     // aggregation + gates
+        KernelProf kp(6, 4.0 * d.H * (lv.level_edges(L) + 2.0 * (p1 - p0)), st);
+        DVAE_TRY(k_prefix_gru_fwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, st));
+      }
       else if (pg) DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));              // GH rows summed by k_agg_fwd
       else DVAE_TRY(gru_rows(p0, p1));
     }
@@ -429,7 +450,10 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       if (seeded) DVAE_TRY(dagg_gemm(0, z1));
       DVAE_TRY(dagg_gemm(R, b.RH));
     }
-    DVAE_TRY(k_dgm_bwd(S, 0, R, b, HP, st));
+    {
+      KernelProf kp(7, 8.0 * d.H * (lv.E + 2.0 * R), st);
+      DVAE_TRY(k_dgm_bwd(S, 0, R, b, HP, st));
+    }
     return DVAE_OK;
   }
   float* dtarget = b.prefix ? b.DHn : b.DH;
@@ -443,7 +467,11 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       if (pg) {
         // dL/dGM[u] = (direct gradients of the rows that hold u) + (their dgh, summed).Whh: the hidden
         // product's input gradient once per node instead of once per prefix row
-        DVAE_TRY(k_dgm_gather(S, ns, ne, b, HP, st));
+        {
+          // the consumers of level L's nodes are the predecessor links of the levels above
+          KernelProf kp(7, 8.0 * d.H * (lv.level_edges(L + 1) + 2.0 * (ne - ns)), st);
+          DVAE_TRY(k_dgm_gather(S, ns, ne, b, HP, st));
+        }
         if (ne - ns <= small_rows) {
           // hidden part of dL/dGM and the gate/map backward in one launch (level.hip small_kernel)
           DVAE_TRY(k_level_gm_bwd_small(ns, ne, b, w.gru.Whh, HP, g.prio, st));
@@ -454,6 +482,7 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
           DVAE_TRY(k_gm_bwd_apply(ns, ne, b, HP, st, &parts));
         }
       } else {
+        KernelProf kp(7, 8.0 * d.H * (lv.level_edges(L + 1) + 2.0 * (ne - ns)), st);
         DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
       }
       if (ne - ns <= small_rows && !b.prefix) {
@@ -794,7 +823,10 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
     DVAE_TRY(k_rows_to_dense(S, R, w.s.Hn, HP, states, d.N, d.H, st));
   }
-  DVAE_TRY(k_pair_fwd(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
+  {
+    KernelProf kp(4, pair_bytes(d, lv), st);
+    DVAE_TRY(k_pair_fwd(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
+  }
   DVAE_TRY(ev.edge(sd, st));
   return DVAE_OK;
 }
@@ -856,6 +888,8 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   // one-pass backward of the pair scorer: small graphs keep every candidate's accumulator on chip, larger
   // ones walk the candidates in register-resident windows; both also sum db1 (the column sums of DBq)
   const bool pair_one_pass = pair_bwd_fused_ok(d.N, EHP) || pair_bwd_win_ok(EHP);
+  {
+  KernelProf pair_prof(5, 2.0 * pair_bytes(d, lv), st);   // scope: the scorer's backward launches
   if (pair_one_pass) {
     // its partial sums carry db1, dw2 and db2, adjacent in the packed layout
     DVAE_REQUIRE(L.w2 == L.b1 + (size_t)EHP && L.b2 == L.w2 + (size_t)EHP, "decoder layout: b1 | w2 | b2 must be adjacent");
@@ -869,6 +903,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
     DVAE_TRY(k_pair_bwd_a(sv, ts, R, RH, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DA, Gp + L.w2, msc.part,
                           msc.part_floats, EHP, st));
     DVAE_TRY(k_pair_bwd_b(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, d_edge, w.DBq, EHP, st));
+  }
   }
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
   // the add_edge weight-gradient products (side stream).  Lab switch: issue them AFTER the chain's own
@@ -963,6 +998,7 @@ extern "C" int dvae_side_stream_create(void** stream_out, int* priority_out) {
   DVAE_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
   *stream_out = (void*)s;
   if (priority_out) *priority_out = prio;
+  DVAE_TRY(elbo_static_warm());   // dvae_elbo_static's per-device symbol look-up, done at set-up (loss.hip)
   return DVAE_OK;
 }
 
@@ -1018,7 +1054,24 @@ StepWs step_ws(const dvae_dims& d, void* base) {
 }
 }  // namespace
 
-extern "C" size_t dvae_step_ws_bytes(const dvae_dims* d) { return step_ws(*d, nullptr).bytes; }
+extern "C" size_t dvae_step_ws_bytes(const dvae_dims* d) {
+  if (!d || d->HP <= 0) {
+    dvae_set_error("step_ws_bytes: null or uninitialised dims (call dvae_dims_init)");
+    return 0;
+  }
+  return step_ws(*d, nullptr).bytes;
+}
+
+// the two dims of a step describe ONE batch: ws_step is carved from d_dec while the encoder writes mu / logvar sized
+// by d_enc, so a mismatched pair would overrun it
+static int step_dims_ok(const dvae_dims& de, const dvae_dims& dd) {
+  DVAE_REQUIRE(de.HP > 0 && dd.HP > 0, "step: dims not initialised (call dvae_dims_init)");
+  DVAE_REQUIRE(de.B == dd.B && de.N == dd.N && de.C == dd.C && de.H == dd.H && de.HP == dd.HP && de.Z == dd.Z &&
+                   de.mod == dd.mod,
+               "step: d_enc and d_dec disagree (B %d/%d N %d/%d C %d/%d H %d/%d Z %d/%d mod %d/%d)", de.B, dd.B, de.N, dd.N,
+               de.C, dd.C, de.H, dd.H, de.Z, dd.Z, de.mod, dd.mod);
+  return DVAE_OK;
+}
 
 extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stream) {
   DVAE_REQUIRE(s && s->d_enc && s->d_dec && s->g && s->x && s->sched && s->info_host && s->Pe && s->Pd && s->ws_enc &&
@@ -1026,6 +1079,7 @@ extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stre
                "step_part1: null pointer");
   const dvae_dims& de = *s->d_enc;
   const dvae_dims& dd = *s->d_dec;
+  DVAE_TRY(step_dims_ok(de, dd));
   hipStream_t st = (hipStream_t)stream;
   hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
   Events& ev = g_events;
@@ -1057,6 +1111,7 @@ extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stre
 extern "C" int dvae_step_part2(const dvae_step* s, void* stream, void* side_stream) {
   DVAE_REQUIRE(s && s->d_enc && s->d_dec && s->x && s->sched && s->info_host && s->Pe && s->ws_enc && s->ws_step && s->Ge,
                "step_part2: null pointer");
+  DVAE_TRY(step_dims_ok(*s->d_enc, *s->d_dec));
   const StepWs w = step_ws(*s->d_dec, s->ws_step);
   return dvae_encoder_bwd(s->d_enc, s->x, s->sizes, s->sched, s->info_host, s->Pe, s->ws_enc, nullptr, w.d_mu,
                           w.d_logvar, s->Ge, stream, side_stream);

@@ -447,6 +447,8 @@ void prof_end(GemmProf* r, hipStream_t st) {
 // the fused level-step kernels (level.hip) run the same MFMA main loop and are counted
 // with the NT launches
 void* gemm_prof_begin(double flops, hipStream_t st) { return prof_begin(0, flops, st); }
+// the HBM-bound kernels bench.py reports beside the GEMM (tags 4..7, `flops` carries their algorithmic BYTES)
+void* kernel_prof_begin(int tag, double bytes, hipStream_t st) { return prof_begin(tag, bytes, st); }
 void gemm_prof_end(void* h, hipStream_t st) { prof_end(static_cast<GemmProf*>(h), st); }
 
 namespace {
@@ -628,6 +630,23 @@ extern "C" int dvae_gemm_profile(int enable) {
   return DVAE_OK;
 }
 
+// the HBM-bound kernels of the same log: out12 = 4 x {launches, ms, algorithmic bytes} for
+// 0 pair scorer forward, 1 pair scorer backward, 2 aggregation forward, 3 aggregation backward.
+// Does not clear the log: call it BEFORE dvae_gemm_profile_read.
+extern "C" int dvae_hbm_profile_read(double* out12) {
+  for (int i = 0; i < 12; ++i) out12[i] = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    GemmProf& r = g_prof.recs[i];
+    if (r.variant < 4 || r.variant > 7) continue;
+    DVAE_CHECK_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    DVAE_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    double* o = out12 + 3 * (r.variant - 4);
+    o[0] += 1.0; o[1] += ms; o[2] += r.flops;
+  }
+  return DVAE_OK;
+}
+
 extern "C" int dvae_gemm_profile_read(double* out12) {
   for (int i = 0; i < 12; ++i) out12[i] = 0.0;
   // slot 2 (layout index 2 is unused): out12[6] = wall time during which at least one GEMM
@@ -639,6 +658,7 @@ extern "C" int dvae_gemm_profile_read(double* out12) {
     DVAE_CHECK_HIP(hipEventSynchronize(r.b));
     float ms = 0.f, t0 = 0.f;
     DVAE_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    if (r.variant > 3) continue;   // an HBM-kernel record (dvae_hbm_profile_read)
     double* o = out12 + 3 * (r.variant & 3);
     o[0] += 1.0; o[1] += ms; o[2] += r.flops;
     if (hipEventElapsedTime(&t0, g_prof.recs[0].a, r.a) == hipSuccess) iv.push_back({t0, (double)t0 + ms});

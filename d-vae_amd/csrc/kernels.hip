@@ -1513,6 +1513,10 @@ int k_graph_state_bwd(const SchedDir& S, int R, int B, int N, int mod, const int
   return DVAE_OK;
 }
 
+// shapes the LDS-sliced forward scorer covers, and the candidates per Bq window it takes there
+static bool pair_fwd_slice_shape(int N, int EHP) { return N > 16 && N <= 128 && EHP % PF_SL == 0; }
+static int pair_fwd_slice_window(int N) { return N <= 64 ? N : 56; }
+
 int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,
                const float* Cq, const float* w2, const float* b2, float* edge_logits, int EHP, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
@@ -1520,8 +1524,8 @@ int k_pair_fwd(const SchedView& sv, const TypeShare& ts, int R, const int* sizes
   static const int cap = getenv("DVAE_PAIR_FWD_GRID") ? atoi(getenv("DVAE_PAIR_FWD_GRID")) : 4096;   // lab
   // graphs of more than 16 nodes: Bq windows in LDS, the add_edge width in slices (DVAE_NO_PAIR_FWD_SLICE=1: A-B tests)
   static const bool no_slice = getenv("DVAE_NO_PAIR_FWD_SLICE") != nullptr;
-  if (!by_rows && !no_slice && sv.N > 16 && sv.N <= 128 && EHP % PF_SL == 0) {
-    const int CW = sv.N <= 64 ? sv.N : 56;
+  if (!by_rows && !no_slice && pair_fwd_slice_shape(sv.N, EHP)) {
+    const int CW = pair_fwd_slice_window(sv.N);
     const size_t lds_bytes = ((size_t)CW * PF_SL + (size_t)sv.N * CW) * sizeof(float);   // <= 143 KB
     static std::once_flag big_lds[16];   // per device: more than 64 KB of LDS is opt-in
     int dev = 0;
@@ -1634,6 +1638,18 @@ int k_pair_bwd_win(const SchedView& sv, const TypeShare& ts, int R, const int* s
   DVAE_LAUNCH_CHECK();
   const size_t used = (size_t)grid * per;
   return reduce_parts_2stage(part, (int)grid, per, part + used, part_floats - used, out, per, st);
+}
+
+// test surface: which pair-scorer kernels a batch of N-node graphs with add_edge width EHP runs on (the same
+// predicates the launchers above use; environment overrides for A-B runs aside)
+//   1 forward = pair_fwd_slice_kernel   2 ... with more than one Bq window   4 backward = pair_bwd_fused_kernel
+//   8 backward = pair_bwd_win_kernel    (no backward bit: the two-kernel pair_bwd_a + pair_bwd_b)
+extern "C" int dvae_pair_path(int N, int EHP) {
+  int bits = 0;
+  if (pair_fwd_slice_shape(N, EHP)) bits |= 1 | (pair_fwd_slice_window(N) < N ? 2 : 0);
+  if (pair_bwd_fused_ok(N, EHP)) bits |= 4;
+  else if (pair_bwd_win_ok(EHP)) bits |= 8;
+  return bits;
 }
 
 int k_pair_bwd_b(const SchedView& sv, const TypeShare& ts, int R, const int* sizes, const float* A, const float* Bq,

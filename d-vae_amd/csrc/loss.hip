@@ -139,6 +139,13 @@ __global__ __launch_bounds__(256) void elbo_final_kernel(const double* __restric
 
 }  // namespace
 
+// set-up hook (dvae_side_stream_create): resolve the static array's address on the current device now, so
+// that no symbol look-up is left for a first dvae_elbo_static call made under stream capture
+int elbo_static_warm() {
+  double* p = nullptr;
+  return elbo_scratch_ptr(&p);
+}
+
 extern "C" int dvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, long long n,
                                 void* stream) {
   if (n <= 0) return DVAE_OK;

@@ -13,7 +13,16 @@
 //     a1b1, a1b2, a2b1, a1b3, a2b2, a3b1
 // carry everything above 2^-24 |a b|, which is fp32's own rounding step (the dropped a2b3 + a3b2 + a3b3 are
 // ~2^-25 |a b| on average).  So six bf16 MFMAs give the fp32 product at 16 / 6 = 2.7 x the fp32 MFMA rate, with
-// fp32 accumulation as before.  Operands are split while they are staged into LDS (5.5 VALU operations per
+// fp32 accumulation as before.
+// WORST CASE (not the average): truncation gives |x2| < 2^-7 |x| and |x3| < 2^-15 |x|, so the dropped products of one
+// a*b are below (2^-22 + 2^-22 + 2^-30) |a b| < 2^-21 |a b|, and they all carry the sign of a*b (truncation rounds
+// every piece towards zero): a dot product is off by less than 2^-21 sum_k |a_k||b_k| towards zero, on top of the
+// fp32 accumulation error, whatever K is and whatever the signs are -- the bias does not average out on same-sign
+// operands, but it cannot exceed this bound either (tests/test_gpu_kernels.py: K = 57344 same-sign operands,
+// all-ones significands, denormals).  The maximum is reached by significands that are all ones (2^-23 |a b|).
+// Non-finite operands: split3(+-inf) = (inf, inf - inf = NaN, NaN), so an inf operand gives NaN where the fp32 MFMA
+// gives inf; NaN stays NaN.  Non-finite in, non-finite out -- but inf is not preserved as inf.  Denormal pieces may be
+// flushed by the matrix pipe; they are below 2^-126 and only matter for dot products that are denormal throughout.  Operands are split while they are staged into LDS (5.5 VALU operations per
 // element, once per k-tile) and kept as three planes of bf16 in the layout the 32x32x16 fragment read wants:
 //     plane[p][k-octet o][row r] = 8 bf16 (16 bytes) = pieces p of k = 8o .. 8o+7 of row r
 // so a lane's fragment is one ds_read_b128 and 16 lanes of a read group touch 16 consecutive 16-byte slots.

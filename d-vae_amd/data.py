@@ -101,10 +101,14 @@ class ScheduledLoader:
     (dataloader.py:104-108) is kept: at 256 bytes per 8-node graph the device-side build (~30 us per
     batch) is cheaper than any host-side CSR."""
 
-    def __init__(self, loader, model, shard=None):
-        self.loader, self.model, self.shard = loader, model, shard
+    def __init__(self, loader, model, shard=None, on_side_stream=False):
+        # on_side_stream: build the schedules on the library's side stream instead of a third stream of this
+        # process (Dvae.prepare) -- for processes that also hold RCCL's streams (4 hardware queues per process)
+        self.loader, self.model, self.shard, self.on_side_stream = loader, model, shard, on_side_stream
 
     def __len__(self):
+        if not hasattr(self.loader, '__len__'):
+            raise TypeError("the wrapped loader (%s) has no length" % type(self.loader).__name__)
         return len(self.loader)
 
     def _stage(self, batch):
@@ -112,7 +116,7 @@ class ScheduledLoader:
         if self.shard is not None:
             batch = self.shard(batch)
         batch = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
-        return batch, self.model.prepare(batch)          # prepare() orders its stream after the copies
+        return batch, self.model.prepare(batch, on_side_stream=self.on_side_stream)   # prepare() orders its stream after the copies
 
     def __iter__(self):
         it = iter(self.loader)

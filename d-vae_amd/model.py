@@ -8,6 +8,7 @@ reference's key names); no torch op touches the hot path.
 """
 import ctypes
 
+import os
 import torch
 import torch.nn as nn
 

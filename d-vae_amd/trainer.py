@@ -62,6 +62,8 @@ class Trainer:
                       `training_step(...)['loss'].backward()` through autograd
     dist              torch.distributed module (initialised) for data-parallel runs: every rank
                       trains on its shard of each batch, gradients are SUM all-reduced (dp.py)
+    A batch dict may carry 'eps' [B,Z]: the reparameterisation draw per GLOBAL graph index (sharded with the
+    batch), which makes a data-parallel run reproduce the single-device one; without it every rank draws its own.
     """
 
     def __init__(self, max_epochs=300, save_dir=None, fused=True, dist=None, keep_all=False, log=print,
@@ -111,13 +113,16 @@ class Trainer:
                     if world > 1 and next(v for v in b.values() if torch.is_tensor(v)).shape[0] < world:
                         return None
                     return dp.shard_batch(b, rank, world) if world > 1 else b
-                loader = ScheduledLoader((b for b in (stage(raw) for raw in loader) if b is not None), model)
+                # with a collective library in the process the schedules are built on the library's side stream, not on
+                # a third stream (4 hardware queues per process; bench.py does the same)
+                loader = ScheduledLoader((b for b in (stage(raw) for raw in loader) if b is not None), model,
+                                         on_side_stream=world > 1)
             for i, item in enumerate(loader):
                 if self.max_steps is not None and i >= self.max_steps:
                     break
                 if prepared:
                     batch, level_sched = item
-                    out4 = model.loss_and_grad(batch, grad_sync=sync, sched=level_sched)
+                    out4 = model.loss_and_grad(batch, eps=batch.get('eps'), grad_sync=sync, sched=level_sched)
                     opt.step()
                     sums += dp.allreduce_losses(self.dist, out4.detach().clone()).double().cpu()
                     steps += 1
@@ -128,7 +133,7 @@ class Trainer:
                                 # reference's loader has no drop_last, dataloader.py:118-126): all ranks drop it
                 batch = _to_device(dp.shard_batch(batch, rank, world) if world > 1 else batch, dev)
                 if fused:
-                    out4 = model.loss_and_grad(batch, grad_sync=sync)
+                    out4 = model.loss_and_grad(batch, eps=batch.get('eps'), grad_sync=sync)
                 else:
                     opt.zero_grad(set_to_none=True)
                     out = model.training_step(batch, i)

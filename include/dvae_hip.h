@@ -108,6 +108,11 @@ int dvae_gemm_tune(int splitk_blocks, int force_prio);   /* tuning knobs: workgr
                                                            (0 = keep), wave priority override (-1 = caller's) */
 int dvae_gemm_profile(int enable);
 int dvae_gemm_profile_read(double* out12_host);
+/* The same log also brackets the HBM-bound kernels north_star names (gated-sum aggregation, dvae_model.py:77-80, and
+ * edge scoring, :211-219): out12 = 4 x {launches, ms, ALGORITHMIC bytes} for 0 pair scorer forward,
+ * 1 pair scorer backward, 2 aggregation forward (agg_fwd, prefix_gru_fwd), 3 aggregation backward (dgm_bwd, dgm_gather).
+ * Does not clear the log: call it before dvae_gemm_profile_read. */
+int dvae_hbm_profile_read(double* out12_host);
 
 /* ------------------------------------------------------------------------
  * Level scheduler.  The reference walks nodes in index order
@@ -276,6 +281,11 @@ int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share);
  * reduction split over the waves of a workgroup, gates fused into the forward products; default 1024, environment
  * DVAE_SMALL_ROWS); 0 = never.  Same formulas either way (fp32 summation order differs). */
 int dvae_small_rows_tune(int rows);
+/* test surface (no counterpart in the reference): which kernels score add_edge's pairs (dvae_model.py:210-220) for
+ * graphs of up to N nodes at add_edge width EHP (dvae_dims.EHP).  Bits: 1 forward on the LDS-sliced scorer, 2 with more
+ * than one window of candidate rows, 4 backward fused per graph (accumulators on chip), 8 backward windowed one-pass;
+ * no backward bit = the two-kernel backward.  The parity tests assert that a case runs the kernels it is meant for. */
+int dvae_pair_path(int N, int EHP);
 /* tuning / test knob: share of a sweep's rows whose weight-gradient products are issued on the
  * side stream while the backward sweep is still running (default 0.35; 0 = none), and the row
  * count below which a sweep has no early chunk (default 16384). */
@@ -302,7 +312,7 @@ int dvae_reparam_bwd(const float* d_z, const float* logvar, const float* eps, fl
  * NxN block of each graph (n_b x n_b for ragged graphs), -sum log_softmax*x,
  * KL.  out4 = {edge_loss, vertex_loss, kl_loss, loss} (device, 4 floats).
  * When d_edge/d_type/d_mu/d_logvar are non-NULL the gradients of `loss` are
- * written in the same pass (scaled by *grad_scale if non-NULL, device scalar).
+ * written in the same pass.
  * partial: workspace of dvae_elbo_ws_bytes(B) bytes.
  * ---------------------------------------------------------------------- */
 size_t dvae_elbo_ws_bytes(int B);
@@ -315,8 +325,11 @@ int dvae_elbo(const dvae_dims* d, const float* edge_logits, const float* type_lo
  * serving / evaluation loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.
  * Same arguments as dvae_elbo minus `partial`: the per-graph partial sums live in a file-scope
  * device array inside the library (1.5 MiB per GPU, held until the process ends), whose address is
- * resolved with hipGetSymbolAddress on the first call on each device.  The call itself performs no
- * hipMalloc / hipFree.  Limit: d->B <= 65536 graphs (DVAE_ERR_ARG beyond that).  All calls on one
+ * resolved with hipGetSymbolAddress once per device: by dvae_side_stream_create() on that device (the
+ * library's set-up call) or else by the first dvae_elbo_static call there.  That look-up (hipGetDevice +
+ * hipGetSymbolAddress, which may load the code object) must NOT happen inside a stream capture: a caller that
+ * captures graphs either creates the side stream first or makes one warm-up call outside the capture.  The
+ * call itself performs no hipMalloc / hipFree.  Limit: d->B <= 65536 graphs (DVAE_ERR_ARG beyond that).  All calls on one
  * GPU share the array: calls that overlap on one GPU (two streams, two threads) race; calls ordered
  * on one stream are safe.  Results are bit-identical to dvae_elbo's. */
 #define DVAE_ELBO_STATIC_MAX_B 65536

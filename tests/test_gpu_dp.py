@@ -113,3 +113,127 @@ def test_svae_two_ranks_equal_the_big_batch():
         mp.spawn(_svae_worker, args=(world, port, ret), nprocs=world, join=True)
         assert ret['rows'] == 6
         assert ret['loss_err'] < 1e-5 and ret['grad_rel'] < 1e-5, dict(ret)
+
+
+class _ThreadDist:
+    """Two data-parallel ranks as two THREADS of one process (each with its own model, streams and Trainer) and the
+    collectives as thread rendezvous on the card.  Two PROCESSES sharing one card time-slice it: a multi-step run
+    with cross-stream events takes tens of seconds per step there (the one-step tests above stay under that), and
+    on a real node every rank has a card of its own.  Same interface as torch.distributed where dp.py / Trainer use it."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __init__(self, world):
+        import threading
+        self.world, self.local = world, threading.local()
+        self.barrier_ = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    def is_initialized(self):
+        return True
+
+    def get_rank(self, group=None):
+        return self.local.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def _exchange(self, t):
+        torch.cuda.current_stream().synchronize()          # this rank's producer work is done
+        self.slots[self.local.rank] = t
+        self.barrier_.wait()
+        peers = list(self.slots)
+        return peers
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        peers = self._exchange(t)
+        total = torch.stack([p.detach().to(t.device) for p in peers]).sum(0)
+        torch.cuda.current_stream().synchronize()
+        self.barrier_.wait()                                # everyone has read everyone's input
+        t.copy_(total)
+        torch.cuda.current_stream().synchronize()
+        self.barrier_.wait()
+        return self._Done() if async_op else None
+
+    def broadcast(self, t, src, group=None, async_op=False):
+        peers = self._exchange(t)
+        val = peers[src].detach().clone()
+        torch.cuda.current_stream().synchronize()
+        self.barrier_.wait()
+        t.copy_(val)
+        torch.cuda.current_stream().synchronize()
+        self.barrier_.wait()
+
+
+def _fused_trainer_rank(rank, td, hp, batches, out):
+    import dvae_amd
+    from dvae_amd import trainer
+    from helpers import fill_weights
+    try:
+        td.bind(rank)
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(torch.cuda.Stream(dev)):      # a main stream of its own per rank
+            model = fill_weights(dvae_amd.Dvae(hp), 7 + rank).to(dev)   # ranks start apart: rank 0's weights win
+            model.train_dataloader = lambda: list(batches)
+            model.val_dataloader = lambda: None
+            hist = trainer.Trainer(max_epochs=1, dist=td, fused=True, log=lambda r: None).fit(model)
+            torch.cuda.synchronize()
+            out[rank] = (hist, torch.cat([p.detach().flatten() for p in model.parameters()]).clone(),
+                         torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+    except BaseException as e:                                # a dead rank must not leave the other at a barrier
+        out[rank] = e
+        td.barrier_.abort()
+        raise
+
+
+def test_fused_trainer_two_ranks_equals_single_device(cuda):
+    """Trainer.fit(fused=True) under data parallelism: ScheduledLoader stages every batch one ahead and builds its
+    level schedule on the library's SIDE stream (world > 1), rank 0's parameters and the per-epoch shuffle seed are
+    broadcast, gradients are SUM all-reduced per flat buffer, a tail batch with fewer graphs than ranks is dropped
+    by every rank -- and the result is the single-device run on the whole batches."""
+    import threading
+    import dvae_amd
+    from helpers import fill_weights
+    hp = Namespace(dataset_file=None, mod=None, bidirectional=True, num_classes=6, max_seq=8, hidden_state_size=64)
+    gen = torch.Generator().manual_seed(5)
+    batches = []
+    for i, nb in enumerate((11, 8, 13, 1)):                                  # the last one: fewer graphs than ranks
+        g, x = dvae_amd.synth.random_dags(nb, 8, 6, 0.35, 40 + i, chain=True)
+        batches.append({'graph': g, 'node_encoding': x, 'eps': torch.randn(nb, 56, generator=gen)})
+    td, out = _ThreadDist(2), {}
+    threads = [threading.Thread(target=_fused_trainer_rank, args=(r, td, hp, batches, out)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(100)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck"
+    for r in range(2):
+        assert not isinstance(out.get(r), BaseException), out.get(r)
+    (hist, params, grads), (_, params1, _) = out[0], out[1]
+    ref = fill_weights(dvae_amd.Dvae(hp), 7).to(cuda)
+    start = torch.cat([p.detach().flatten() for p in ref.parameters()]).clone()
+    (opt,), _ = ref.configure_optimizers()
+    losses = []
+    for b in batches[:3]:
+        full = {k: v.to(cuda) for k, v in b.items()}
+        losses.append(float(ref.loss_and_grad(full, eps=full['eps'])[3]))
+        opt.step()
+    torch.cuda.synchronize()
+    rp = torch.cat([p.detach().flatten() for p in ref.parameters()])
+    rg = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    assert hist[0]['steps'] == 3                             # the one-graph tail batch was dropped by both ranks
+    assert torch.equal(params, params1), "the two ranks' parameters differ after the epoch"
+    mean = sum(losses) / 3
+    assert abs(hist[0]['train/loss'] - mean) <= 1e-5 * mean, (hist[0]['train/loss'], mean)
+    assert float((grads - rg).norm() / rg.norm()) < 1e-3
+    # three Adam steps of 1e-4 moved the weights by ~3e-4; the two runs agree far inside that
+    assert float((rp - start).abs().max()) > 2e-4 and float((params - rp).abs().max()) < 3e-5

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
-def test_hip_matches_reference(cuda, name):
+def test_hip_matches_reference(cuda, name, gemm_core):
     from dvae_amd import engine as E
     d, mod, bidir, shared = load_case(name)
     model = build_model(d, mod, bidir, shared, cuda)

@@ -173,6 +173,132 @@ def test_gemm_x6_is_fp32_accurate(cuda, form):
     assert err[1] < 4 * err[0] + 1e-7, err
 
 
+def _both_cores(lib, args, M, N, K, ref, mag):
+    err = {}
+    try:
+        for core_id in (0, 1):
+            lib.dvae_gemm_x6(core_id)
+            out = _gemm(lib, *args, M, N, K)
+            assert torch.isfinite(out).all()
+            err[core_id] = float(((out.double() - ref).abs() / mag).max())
+    finally:
+        lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "1")))
+    return err
+
+
+# x6.h's WORST-CASE bound: the three dropped piece products of one a*b are below (2^-22 + 2^-22 + 2^-30) |a b|, all with
+# the sign of a*b, so a whole dot product is off by less than 2^-21 sum|a||b| on top of the fp32 accumulation error
+X6_DROP = 2.0 ** -21
+
+
+def test_gemm_x6_same_sign_weight_gradient_depth(cuda):
+    """(a) the weight-gradient shape at the headline's depth (TN, K = 57344 rows) on SAME-SIGN operands: the dropped
+    piece products all carry the sign of a*b, so with |randn| operands (post-ReLU activations, dW = dY^T X) their bias
+    adds up linearly in K instead of averaging out -- it must still stay inside the worst-case bound."""
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(11)
+    M, N, K = 256, 128, 57344
+    A, W = torch.randn(K, M, device=cuda).abs(), torch.randn(K, N, device=cuda).abs()
+    ref = A.double().t() @ W.double()
+    err = _both_cores(lib, (A, 1, W, 1), M, N, K, ref, ref)          # sum|a||b| = the product itself here
+    print("same-sign TN K=57344: fp32 MFMA %.2e, bf16x6 %.2e of sum|a||b|" % (err[0], err[1]))
+    assert err[1] <= 2 * err[0] + X6_DROP, err
+    # and as a signed statement: the bias of the x6 result is one-sided (towards zero) and below the bound
+    lib.dvae_gemm_x6(1)
+    try:
+        out = _gemm(lib, A, 1, W, 1, M, N, K)
+    finally:
+        lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "1")))
+    bias = float(((out.double() - ref) / ref).mean())
+    print("mean signed relative error %.2e" % bias)
+    assert abs(bias) < X6_DROP
+
+
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+def test_gemm_x6_adversarial_mantissas(cuda, form):
+    """(b) operands whose 24 significand bits are all ones (maximal second and third pieces: the dropped products are
+    as large as they can get), mixed signs and exponents; (c) a row of denormal-range values beside normal ones and a
+    row that is denormal throughout."""
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(12)
+    M, N, K = 256, 256, 2048
+    ones = lambda *s: (torch.full(s, 2.0 - 2.0 ** -23, device=cuda) * torch.exp2(torch.randint(-3, 4, s, device=cuda).float())
+                       * (torch.randint(0, 2, s, device=cuda).float() * 2 - 1))
+    tiny = torch.finfo(torch.float32).tiny
+
+    def build(rows, cols, kdim):   # kdim: which axis is the reduction
+        X = ones(rows, cols)
+        den = (torch.rand(K, device=cuda) * tiny)                      # denormal-range magnitudes
+        if kdim == 1:
+            X[1, ::2] = den[::2]                                       # denormals beside normal values
+            X[2, :] = den                                              # a row that is denormal throughout
+        else:
+            X[::2, 1] = den[::2]
+            X[:, 2] = den
+        return X
+    if form == "nt":
+        A, W = build(M, K, 1), ones(N, K)
+        ref, args, mag = A.double() @ W.double().t(), (A, 0, W, 0), A.abs().double() @ W.abs().double().t()
+    elif form == "nn":
+        A, W = build(M, K, 1), ones(K, N)
+        ref, args, mag = A.double() @ W.double(), (A, 0, W, 1), A.abs().double() @ W.abs().double()
+    else:
+        A, W = build(K, M, 0), ones(K, N)
+        ref, args, mag = A.double().t() @ W.double(), (A, 1, W, 1), A.abs().double().t() @ W.abs().double()
+    keep = torch.ones(M, dtype=torch.bool, device=cuda)
+    keep[2] = False                                                    # the all-denormal row: absolute check below
+    try:
+        outs = {}
+        for core_id in (0, 1):
+            lib.dvae_gemm_x6(core_id)
+            outs[core_id] = _gemm(lib, *args, M, N, K)
+    finally:
+        lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "1")))
+    err = {c: float(((o.double() - ref).abs() / mag)[keep].max()) for c, o in outs.items()}
+    print("all-ones mantissas: fp32 MFMA %.2e, bf16x6 %.2e of sum|a||b|" % (err[0], err[1]))
+    assert err[1] <= 2 * err[0] + X6_DROP, err
+    for o in outs.values():
+        assert torch.isfinite(o).all()
+        # a dot product of denormals with values <= 16: exact result below K * 16 * tiny; either core may flush
+        # denormal inputs or results to zero, neither may produce anything larger
+        assert float(o[2].abs().max()) <= 16 * K * tiny
+        assert float((o[2].double() - ref[2]).abs().max()) <= 16 * K * tiny
+
+
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+def test_gemm_x6_non_finite_operands(cuda, form, core):
+    """(d) non-finite in, non-finite out, on both cores.  One +inf and one NaN operand: every output that meets them is
+    non-finite and every other output is untouched.  The x6 core turns an inf operand into NaN (split3(inf) has
+    second piece inf - inf = NaN; documented in x6.h), the fp32 MFMA keeps inf where no 0 * inf occurs."""
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(13)
+    M, N, K = 192, 160, 512
+    if form == "tn":
+        A, W = torch.randn(K, M, device=cuda), torch.randn(K, N, device=cuda)
+        A[7, 3], A[400, 100] = float("inf"), float("nan")
+        args, ref = (A, 1, W, 1), None
+        clean = torch.nan_to_num(A, nan=0.0, posinf=0.0).double().t() @ W.double()
+    else:
+        A = torch.randn(M, K, device=cuda)
+        W = torch.randn(N, K, device=cuda) if form == "nt" else torch.randn(K, N, device=cuda)
+        A[3, 7], A[100, 400] = float("inf"), float("nan")
+        args = (A, 0, W, 0 if form == "nt" else 1)
+        Wd = W.double().t() if form == "nt" else W.double()
+        clean = torch.nan_to_num(A, nan=0.0, posinf=0.0).double() @ Wd
+    out = _gemm(lib, *args, M, N, K)
+    bad = torch.zeros(M, dtype=torch.bool, device=cuda)
+    bad[3] = bad[100] = True
+    assert not torch.isfinite(out[bad]).any()
+    assert torch.isnan(out[100]).all()
+    if core == 0:
+        assert torch.isinf(out[3]).all()          # fp32 MFMA: inf * finite = inf
+    assert torch.isfinite(out[~bad]).all()
+    assert torch.allclose(out[~bad].double(), clean[~bad], rtol=1e-5, atol=1e-4 * K ** 0.5)
+
+
 @pytest.mark.parametrize("B,N,p,ragged", [(64, 8, 0.5, False), (33, 20, 0.2, False), (16, 128, 0.05, False),
                                           (50, 40, 0.15, True), (7, 1, 0.5, False)])
 def test_schedule_bit_exact(cuda, B, N, p, ragged):

@@ -105,8 +105,65 @@ def test_ragged_110_nodes_bidirectional_against_oracle(cuda):
         close_scaled(p.grad, sd[k].grad, tol=3e-4, what="grad " + k)
 
 
+def test_ragged_90_nodes_hs256_multiwindow_pair_kernels_against_oracle(cuda):
+    """Config 4's PRODUCTION pair kernels against the dense oracle (dvae_model.py:196-259): at hidden_state_size = 256
+    the add_edge width is EHP = 1024, which selects pair_fwd_slice_kernel -- with max_seq > 64 in windows of 56
+    candidates, so the 90-node graph takes two windows -- and pair_bwd_win_kernel (whole groups of 1024 columns),
+    where the 110-node hs = 64 case above runs the fallback scorers.  Ragged, bidirectional, sizes {90, 23}:
+    decoder states, edge and type logits, the four losses and every gradient."""
+    import dvae_amd
+    from dvae_amd import _lib
+    from oracle import dense_ref as O
+    H, C, Nmax = 256, 6, 96
+    dims = _lib.make_dims(2, Nmax, C, H, 56, None, False, Nmax)
+    assert dims.EHP == 1024
+    path = _lib.load().dvae_pair_path(Nmax, dims.EHP)
+    assert path == (1 | 2 | 8), "expected sliced multi-window forward + windowed backward, got %d" % path
+    sizes = torch.tensor([90, 23], dtype=torch.int32)
+    B = int(sizes.numel())
+    g = torch.zeros(B, Nmax, Nmax)
+    x = torch.zeros(B, Nmax, C)
+    for b, n in enumerate(sizes.tolist()):
+        gb, xb = dvae_amd.synth.random_dags(1, n, C, min(0.5, 4.0 / n), seed=700 + b)
+        g[b, :n, :n], x[b, :n] = gb[0], xb[0]
+    # candidates beyond the first window must carry edges, or the second window is never exercised
+    assert g[0, :90, 56:90].sum() > 0
+    hp = Namespace(dataset_file=None, mod=None, bidirectional=True, num_classes=C, max_seq=Nmax, hidden_state_size=H)
+    model = fill_weights(dvae_amd.Dvae(hp), seed=35).to(cuda)
+    eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(4))
+    sd = oracle_sd(model, requires_grad=True)
+    o = O.train_loss_ragged(sd, g, x, sizes, eps, None, True)
+    o[0].backward()
+    X = {'graph': g.to(cuda), 'node_encoding': x.to(cuda), 'sizes': sizes.to(cuda)}
+    with torch.no_grad():
+        sd0 = {k: v.detach() for k, v in sd.items()}
+        _, mu, lv = model.encoder(X)
+        z = torch.zeros(B, 56)
+        per = []
+        for b, n in enumerate(sizes.tolist()):
+            _, o_mu, o_lv = O.encoder_forward(sd0, g[b:b + 1, :n, :n], x[b:b + 1, :n], None, True)
+            close_scaled(mu[b:b + 1], o_mu, what="mu of graph %d" % b)
+            close_scaled(lv[b:b + 1], o_lv, what="logvar of graph %d" % b)
+            z[b:b + 1] = O.reparameterize(o_mu, o_lv, eps[b:b + 1])
+            per.append(O.decoder_forward(sd0, z[b:b + 1], g[b:b + 1, :n, :n], x[b:b + 1, :n], None, return_states=True))
+        e, t = model.decoder(z.to(cuda), X)
+        hd = model.decoder.node_states(z.to(cuda), X)
+        for b, n in enumerate(sizes.tolist()):
+            o_e, o_t, o_hd, _ = per[b]
+            close_scaled(hd[b:b + 1, :n], o_hd, what="decoder states (%d nodes)" % n)
+            close_scaled(e[b:b + 1, :n, :n], o_e, what="edge logits (%d nodes)" % n)
+            close_scaled(t[b:b + 1, :n], o_t, what="type logits (%d nodes)" % n)
+            assert not e[b, n:].any() and not e[b, :, n:].any() and not t[b, n:].any()
+    out = model.training_step(X, 0, eps=eps.to(cuda))
+    for k, ref in zip(('train/loss', 'train/edge_loss', 'train/vertex_loss', 'train/kl_loss'), o[:4]):
+        assert abs(out['log'][k] - float(ref)) <= 1e-4 * abs(float(ref)) + 1e-5, (k, out['log'][k], float(ref))
+    out['loss'].backward()
+    for k, p in model.named_parameters():
+        close_scaled(p.grad, sd[k].grad, tol=3e-4, what="grad " + k)
+
+
 @pytest.mark.parametrize("name", ["enas_val8_none_bidir", "rand8_none_uni", "rand10_bn_bidir_shared"])
-def test_golden_elementwise_rtol(cuda, name, record_property):
+def test_golden_elementwise_rtol(cuda, name, record_property, gemm_core):
     """north_star's bar read element by element: |hip - reference| <= 1e-6 + 1e-4 |reference| for every
     per-node hidden state, mu, logvar and loss of the reference's golden vectors (the other tests take
     1e-4 of the tensor's scale).  The worst element-wise relative error is recorded with the result."""

@@ -50,7 +50,6 @@ def test_elbo_static_matches_elbo_twice_second_smaller(cuda):
     for B, seed, ragged, beta in ((4096, 1, False, 0.005), (37, 2, True, 0.3)):
         dims = _lib.make_dims(B, N, C, 501, Z, None, False, N)
         inp = _inputs(B, N, C, Z, seed, cuda, ragged)
-        before = torch.cuda.memory_allocated(cuda)
         (want4, wantg), (got4, gotg) = _run(lib, lib.dvae_elbo_static, dims, inp, beta, cuda)
         assert torch.isfinite(want4).all() and torch.equal(got4, want4), (B, got4, want4)
         for a, b in zip(gotg, wantg):
@@ -63,7 +62,32 @@ def test_elbo_static_matches_elbo_twice_second_smaller(cuda):
             ref_k = -0.5 * torch.sum(1 + lv.double() - mu.double() ** 2 - lv.double().exp())
             ref = torch.stack([ref_e, ref_v, ref_k, ref_e + ref_v + beta * ref_k]).float()
             assert torch.allclose(got4, ref, rtol=1e-5), (got4, ref)
-        del before
+
+
+def test_elbo_static_allocates_nothing(cuda):
+    """The property the entry point is named for: the device's free memory (hipMemGetInfo, which sees every
+    hipMalloc of the process, the library's included -- torch's own counters would not) is the same before and
+    after a run of calls.  One warm-up call first: it resolves the array's address and may load the code object."""
+    from dvae_amd import _lib
+    from dvae_amd.engine import _ptr, _stream
+    from dvae_amd._lib import check
+    lib = _lib.load()
+    B, N, C, Z = 512, 8, 8, 56
+    dims = _lib.make_dims(B, N, C, 501, Z, None, False, N)
+    el, tl, g, x, sizes, mu, lv = _inputs(B, N, C, Z, 3, cuda, False)
+    out4 = torch.empty(4, device=cuda)
+    grads = [torch.empty_like(t) for t in (el, tl, mu, lv)]
+    args = [ctypes.byref(dims), _ptr(el), _ptr(tl), _ptr(g), _ptr(x), None, _ptr(mu), _ptr(lv), ctypes.c_float(0.005),
+            _ptr(out4), *[_ptr(t) for t in grads], _stream()]
+    check(lib.dvae_elbo_static(*args))                 # warm-up
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(cuda)
+    for _ in range(50):
+        check(lib.dvae_elbo_static(*args))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(cuda)
+    assert free1 == free0, "free device memory moved by %d bytes over 50 calls" % (free0 - free1)
+    assert torch.isfinite(out4).all()
 
 
 def test_elbo_static_rejects_batches_beyond_its_array(cuda):
