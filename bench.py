@@ -63,6 +63,11 @@ CONFIGS = {
     "c5": dict(kind="decode", mod=None, bidir=False, N=8, C=8, B=100000,
                workload="config 5: greedy Decoder.predict of 100k latent samples z~N(0,I) to 8-node DAGs",
                metric="DAGs/sec D-VAE decode (100k latents, 8-node, hs=501)"),
+    "c5gen": dict(kind="generate", mod=None, bidir=False, N=8, C=8, B=100000,
+                  workload="config 5, evaluation path: decode 100k latent samples z~N(0,I) and score the decoded DAGs on the "
+                           "device -- validity, uniqueness, novelty against a 4096-graph training batch (Dvae.generation_eval; "
+                           "the reference implements only exact-match reconstruction accuracy, SURVEY.md 8 f2)",
+                  metric="DAGs/sec D-VAE decode + validity/uniqueness/novelty (100k latents, 8-node, hs=501)"),
 }
 
 
@@ -116,7 +121,7 @@ def host_cores():
     return max(1, min(share, avail, nphys)), nphys
 
 
-def cpu_baseline(cfg_name, seconds_budget=20.0):
+def cpu_baseline(cfg_name, seconds_budget=20.0, stochastic=False):
     """The reference's CPU path, restated (oracle/dense_ref.py, checked against the real reference in
     tests/golden), timed on this box's host cores on a bounded sample of the configuration."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -128,22 +133,34 @@ def cpu_baseline(cfg_name, seconds_budget=20.0):
     S = dvae_amd.synth
     N, C, mod, bidir = cfg["N"], cfg["C"], cfg["mod"], cfg["bidir"]
     note = ""
-    if cfg["kind"] == "decode":
+    if cfg["kind"] in ("decode", "generate"):
         model = dvae_amd.Dvae(Namespace(dataset_file=None, mod=mod, bidirectional=False, num_classes=C, max_seq=N))
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
         M = 256
         z = torch.randn(M, Z, generator=torch.Generator().manual_seed(0))
+        uni = None
+        if stochastic:     # the reference draws with torch.multinomial / torch.bernoulli; the port takes uniforms
+            gu = torch.Generator().manual_seed(1)
+            uni = {'type': torch.rand(M, N, generator=gu), 'edge': torch.rand(M, N, N, generator=gu)}
+        score = None
+        if cfg["kind"] == "generate":      # the same report on the host: metrics.py on CPU tensors
+            from dvae_amd import metrics
+            tg, tx = S.enas_like(4096, 4242)
+            score = lambda e, t: metrics.generation_report(e, t, tg, tx, 'enas')
         with torch.no_grad():
             O.decoder_predict(sd, z[:8], N, C, mod)
             t0 = time.perf_counter()
             n = 0
             while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 50):
-                O.decoder_predict(sd, z, N, C, mod)
+                e, t = O.decoder_predict(sd, z, N, C, mod, uniforms=uni)[:2]
+                if score is not None:
+                    score(e, t)
                 n += 1
         dt = (time.perf_counter() - t0) / n
         return {"value": M / dt, "unit": "DAGs/s", "cores": threads, "host_physical_cores": nphys, "kind": "port",
-                "sample": "%d greedy decodes of %d latents by oracle/dense_ref.py decoder_predict, %.0f ms each"
-                          % (n, M, dt * 1e3)}
+                "sample": "%d %s decodes of %d latents by oracle/dense_ref.py decoder_predict%s, %.0f ms each"
+                          % (n, "stochastic (injected uniforms)" if stochastic else "greedy", M,
+                             " + metrics.generation_report on the host" if score is not None else "", dt * 1e3)}
     # dense O(B N^3 H) autograd memory: micro-batches beyond config 1
     if cfg_name in ("headline", "c1"):
         B, N_run, make = 32, N, lambda: S.enas_like(32, 1234)
@@ -271,7 +288,7 @@ def main():
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.steps is None:
-        args.steps = {"headline": 20, "c1": 50, "c2": 20, "c3": 5, "c4": 8, "c5": 3}[args.config]
+        args.steps = {"headline": 20, "c1": 50, "c2": 20, "c3": 5, "c4": 8, "c5": 3, "c5gen": 3}[args.config]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
@@ -327,14 +344,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if cfg["kind"] == "decode":
+    if cfg["kind"] in ("decode", "generate"):
         # embarrassingly parallel: every rank decodes its contiguous shard of the latents, no collective
         z = torch.randn(B_global, Z, generator=torch.Generator().manual_seed(0))[lo:hi].to(dev)
         mean_n, mean_e, mean_pairs = float(N), 0.0, N * (N - 1) / 2
         out = None
+        report = {}
+        if cfg["kind"] == "generate":
+            from dvae_amd import metrics
+            tg, tx = dvae_amd.synth.enas_like(4096, 4242)
+            tg, tx = tg.to(dev), tx.to(dev)
 
         def step(i):
-            return model.decoder.predict(z, is_stochastic=args.stochastic)
+            e, t = model.decoder.predict(z, is_stochastic=args.stochastic)
+            if cfg["kind"] == "generate":     # validity / uniqueness / novelty of this rank's decodes, on the device
+                report.update(metrics.generation_report(e, t, tg, tx, 'enas'))
+            return e, t
     else:
         # Adam(lr=1e-4) on every parameter each step (dvae_model.py:471-475): one fused instance
         if not args.split_optimizer:
@@ -475,6 +500,10 @@ def main():
                        "global_batch": B_global, "per_gpu_batch": B_local, "mean_nodes": round(mean_n, 2),
                        "mean_edges": round(mean_e, 2), "parallelism": "dp%d" % world},
         }
+        if cfg["kind"] != "train":
+            res["config"]["decode"] = "stochastic (device uniforms: inverse-CDF type draw, u < sigmoid edge draw)" if args.stochastic else "greedy"
+        if cfg["kind"] == "generate":
+            res["config"]["report"] = {k: (round(float(v), 6) if isinstance(v, (int, float)) else v) for k, v in report.items()}
         if cfg["kind"] == "train":
             res["config"]["final_loss"] = final
             if cfg["N"] <= 16:
@@ -498,7 +527,7 @@ def main():
             if cfg["kind"] == "train":
                 per_dag = algorithmic_flops(mean_n, mean_e, mean_pairs, cfg["mod"], cfg["bidir"], C)
             else:
-                per_dag = decode_flops(N)
+                per_dag = decode_flops(N)      # the metrics of the evaluation path are integer work on 0/1 tensors
             algo = per_dag * B_local * prof_steps
             busy = gemm[6] if gemm[6] > 0 else kms     # wall time with >= 1 GEMM launch running
             ach = algo / (busy * 1e-3) / 1e12 if busy > 0 else 0.0
@@ -551,7 +580,7 @@ def main():
                     rows.append(row)
                 res["roofline"]["hbm"] = rows
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.config)
+            res["cpu_baseline"] = cpu_baseline(args.config, stochastic=args.stochastic)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -924,7 +924,10 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
       DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
       DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
       DVAE_TRY(k_type_gru_bwd(d.C, sw.gru, w.DTV, w.TG, w.TGN, w.XPT, HP, sd));
-      if (U >= 0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, U, 0, sv.a_rows));
+      // dW1a over the scored edge rows: gathered through the row list, or (DVAE_W1A_TN_ALL=1, lab) over every edge row --
+      // the pair scorer's backward writes zeros into the DA rows no pair is scored on, so both sums are the same
+      static const bool w1a_all = getenv("DVAE_W1A_TN_ALL") != nullptr;
+      if (U >= 0 && !w1a_all) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, U, 0, sv.a_rows));
       else DVAE_TRY(gs.tn(w.DA + (size_t)R * EHP, EHP, w.s.HV + (size_t)R * HP, HP, Gp + L.W1a, HP, EHP, HP, RH - R));
       if (!skip0) DVAE_TRY(gs.tn(w.DA, EHP, w.s.HV, HP, Gp + L.W1a, HP, EHP, HP, z1, 1));
       DVAE_TRY(gs.nn(w.DTT, 32, w.TYPEV, HP, Gp + L.W1a, HP, EHP, HP, 32, 1));
