@@ -921,7 +921,14 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
       //   d hv(type) = DTT^T . W1a  -> GRU backward once per type (k_type_gru_bwd)
       //   dW1a      += DTT . hv(type)
       DVAE_TRY(k_build_xp(S, 1, RH, x, d.N, d.C, w.s.XP, sd));
-      DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
+      // DTT = DA^T . onehot(type) over the k = 0 rows of levels >= 1: a per-type column sum, one streaming pass over DA
+      // (DVAE_NO_TYPED_COLSUM=1: the [EHP x 32] TN product instead; A-B tests)
+      static const bool dtt_gemm = getenv("DVAE_NO_TYPED_COLSUM") != nullptr;
+      if (dtt_gemm)
+        DVAE_TRY(gs.tn(w.DA + (size_t)z1 * EHP, EHP, w.s.XP + (size_t)z1 * 32, 32, w.DTT, 32, EHP, 32, R - z1));
+      else
+        DVAE_TRY(k_typed_colsum(w.DA + (size_t)z1 * EHP, EHP, R - z1, EHP, sv.row_type + z1, d.C, w.DTT, ssc.part,
+                                ssc.part_floats, sd));
       DVAE_TRY(gs.tn(w.DTT, 32, P + L.W1a, HP, w.DTV, HP, 32, HP, EHP));
       DVAE_TRY(k_type_gru_bwd(d.C, sw.gru, w.DTV, w.TG, w.TGN, w.XPT, HP, sd));
       // dW1a over the scored edge rows: gathered through the row list, or (DVAE_W1A_TN_ALL=1, lab) over every edge row --

@@ -33,6 +33,7 @@
 static int g_splitk_blocks = 768;   // tuning knob: workgroups a split-K launch aims for
 static int g_force_prio = -1;       // tuning knob: -1 as requested by the caller, 0/1 override
 static int g_force_splits = 0;      // lab knob: split-K factor for every launch (0 = automatic)
+static int g_mid_split = getenv("DVAE_NO_MID_SPLIT") ? 0 : 1;   // A-B knob for the mid-sized split-K rule below
 extern "C" int dvae_gemm_force_splits(int v) { g_force_splits = v; return 0; }
 static int g_dbg = 0;
 extern "C" int dvae_gemm_dbg(int v) { g_dbg = v; return 0; }
@@ -183,6 +184,150 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int x = bid & 7, j = bid >> 3;
   const int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + j;
+}
+
+// Epilogue shared by the GEMM kernels.  D map of the 32x32 MFMA with the n-operand first (C^T in the accumulator):
+// m = lane&31, n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  ->  reg group g holds n = 8g + 4*(lane>>5) + 0..3
+template <int TM, int TN>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM][TN], const GemmParams& p, float* C, int mbase, int nbase, int lane) {
+  const bool vec = ((p.ldc | p.N) & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                   (!p.bias || ((uintptr_t)p.bias & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = mbase + i * 32 + (lane & 31);
+    if (row >= p.M) continue;
+    float* crow = C + (size_t)(p.row_map ? p.row_map[row] : row) * p.ldc;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = nbase + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (col >= p.N) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        if (vec) {
+          if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          float4* dst = reinterpret_cast<float4*>(crow + col);
+          if (p.accumulate) {
+            const float4 o = *dst;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          if (p.relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+          *dst = v;
+        } else {
+          const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (col + t >= p.N) break;
+            float x = e[t] + (p.bias ? p.bias[col + t] : 0.f);
+            if (p.accumulate) x += crow[col + t];
+            if (p.relu) x = fmaxf(x, 0.f);
+            crow[col + t] = x;
+          }
+        }
+      }
+  }
+}
+
+// the six piece products of one 32-deep k-tile on split operands (x6.h), fragments read from LDS
+template <int TM, int TN, class TA, class TB>
+__device__ __forceinline__ void x6_mma_tile(f32x16 (&acc)[TM][TN], const float* As, const float* Bs, int arow, int brow, int lane) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) af[i][q] = TA::frag(As, q, arow + i * 32, ks, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bf[j][q] = TB::frag(Bs, q, brow + j * 32, ks, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][2], af[i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][1], af[i][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][0], af[i][0], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// In-workgroup split-K ("wsk") form of the x6 kernel for the 4096-row per-level products (round 3).  Their output
+// (4096 x 512) is 512 tiles of 64 x 64 -- two small workgroups per CU, each walking the whole reduction with one
+// fragment read per MFMA and 8 operand bytes per 64 x 64 x 1 MACs -- while larger tiles leave CUs empty.  Here a
+// 512-thread workgroup owns a 128 x 64 tile (256 workgroups, one per CU) and its two groups of four waves take
+// alternate 32-deep k-tiles, each group with its own staging area: per CU the same eight waves, but 0.75 x the operand
+// bytes and 18 fragment reads per 24 MFMAs instead of 12 per 12.  The two partial tiles meet in LDS (group 1 parks,
+// group 0 adds: fixed order) -- no slabs, no combine launch.  A m-major; K % 64 == 0.  tools/bench_level_shapes.py:
+// NN 4096 x 512 x 1536 50.6 -> 45.3 us, x 1024 36.8 -> 31.9 us.
+// ---------------------------------------------------------------------------
+template <int BKM>
+__global__ __launch_bounds__(512, 1) void gemm_wsk_kernel(GemmParams p) {
+  constexpr int BM = 128, BN = 64, WM = 2, WN = 2, TM = 2, TN = 1;
+  using TA = XTile<0, BM>;
+  using TB = XTile<BKM, BN>;
+  constexpr int GROUP = TA::LDS_FLOATS + TB::LDS_FLOATS;
+  constexpr int RED = BM * BN;
+  __shared__ __attribute__((aligned(16))) float lds[2 * GROUP > RED ? 2 * GROUP : RED];
+  if (p.prio) __builtin_amdgcn_s_setprio(2);
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap(blockIdx.x, p.nblk);
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  float* As = lds + grp * GROUP;
+  float* Bs = As + TA::LDS_FLOATS;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  TA ta;
+  TB tb;
+  ta.rows_init(p.lda, m0, p.M, p.row_map, tid);
+  tb.rows_init(p.ldb, n0, p.N, nullptr, tid);
+  const int nt = p.K / 64;   // pairs of k-tiles
+  ta.template load<true>(p.A, p.lda, m0, p.M, grp * 32, p.K, tid);
+  tb.template load<true>(p.B, p.ldb, n0, p.N, grp * 32, p.K, tid);
+  ta.store(As, tid);
+  tb.store(Bs, tid);
+  __syncthreads();
+  for (int t = 0; t + 1 < nt; ++t) {
+    ta.template load<false>(p.A, p.lda, m0, p.M, (t + 1) * 64 + grp * 32, p.K, tid);
+    tb.template load<false>(p.B, p.ldb, n0, p.N, (t + 1) * 64 + grp * 32, p.K, tid);
+    x6_mma_tile<TM, TN, TA, TB>(acc, As, Bs, wm * (BM / WM), wn * (BN / WN), lane);
+    __syncthreads();
+    ta.store(As, tid);
+    tb.store(Bs, tid);
+    __syncthreads();
+  }
+  x6_mma_tile<TM, TN, TA, TB>(acc, As, Bs, wm * (BM / WM), wn * (BN / WN), lane);
+  __syncthreads();
+  float* red = lds;   // [wave][i][reg][lane]
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * TM + i) * 16 + r) * 64 + lane] = acc[i][0][r];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] += red[((wave * TM + i) * 16 + r) * 64 + lane];
+  store_tile<TM, TN>(acc, p, p.C, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
 template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2, bool KG = false, bool X6 = false>
@@ -336,51 +481,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
   }
   if (ST == 1) __syncthreads();
 
-  // epilogue.  D map of the 32x32 MFMA with the operands as above:
-  // m = lane&31, n = (reg&3) + 8*(reg>>2) + 4*(lane>>5)  ->  reg group g holds n = 8g + 4*(lane>>5) + 0..3
+  // epilogue
   float* C = p.C + (size_t)blockIdx.y * p.c_split;
   if ((p.dbg & 1) && acc[0][0][0] != 12345.f) return;
-  const bool vec = ((p.ldc | p.N) & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
-                   (!p.bias || ((uintptr_t)p.bias & 15) == 0);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int row = m0 + wm * (BM / WM) + i * 32 + (lane & 31);
-    if (row >= p.M) continue;
-    float* crow = C + (size_t)(p.row_map ? p.row_map[row] : row) * p.ldc;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int col = n0 + wn * (BN / WN) + j * 32 + 8 * g + 4 * (lane >> 5);
-        if (col >= p.N) continue;
-        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        if (vec) {
-          if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-          }
-          float4* dst = reinterpret_cast<float4*>(crow + col);
-          if (p.accumulate) {
-            const float4 o = *dst;
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-          }
-          if (p.relu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          }
-          *dst = v;
-        } else {
-          const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if (col + t >= p.N) break;
-            float x = e[t] + (p.bias ? p.bias[col + t] : 0.f);
-            if (p.accumulate) x += crow[col + t];
-            if (p.relu) x = fmaxf(x, 0.f);
-            crow[col + t] = x;
-          }
-        }
-      }
-  }
+  store_tile<TM, TN>(acc, p, C, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
 // out[m][n] (+)= sum_s slab[s][m][n] + bias[n]
@@ -478,6 +582,11 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     // small-batch per-level products: a handful of tiles, each walking the whole K
     // loop at one workgroup per CU, is latency-bound -- spread K over the idle CUs
     splits = min(cdiv(256, p.nblk), d.K / 128);
+  } else if (p.nblk < 448 && d.K >= 1024 && ws && !d.bulk && g_mid_split) {
+    // mid-sized per-level products with a long reduction (the backward products of 1.5k .. 3.5k-row levels: K = 2HP,
+    // 3HP): a few hundred 64x64 tiles that each walk 32 .. 48 k-tiles alone leave the chip latency-bound; three or
+    // four K slices per tile fill it (tools/bench_level_shapes.py: 2048 x 512 x 1536 49 -> 30 us incl. the combine)
+    splits = min(cdiv(768, p.nblk), d.K / 256);
   }
   if (g_force_splits > 0 && ws) splits = g_force_splits;
   if (d.row_map) splits = 1;   // the slab reduction does not scatter rows
@@ -530,6 +639,33 @@ int gemm_x6_enabled() { return g_x6; }
 static int g_force_tile = 0;   // tuning knob (tests/bench_gemm.py): 0 auto, 1 128x128, 2 64x128, 3 64x64
 extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE_OK; }
 
+namespace {
+// the in-workgroup split-K kernel: one 128 x 64 tile per workgroup, no slabs
+int launch_wsk(const GemmDesc& d, hipStream_t stream) {
+  GemmParams p;
+  p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias;
+  p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+  p.M = d.M; p.N = d.N; p.K = d.K;
+  p.relu = d.relu; p.accumulate = d.accumulate;
+  p.prio = g_force_prio >= 0 ? g_force_prio : d.prio;
+  p.dbg = 0; p.row_map = d.row_map; p.k_map = nullptr;
+  p.k_chunk = d.K; p.c_split = 0;
+  p.tiles_n = cdiv(d.N, 64);
+  p.nblk = cdiv(d.M, 128) * p.tiles_n;
+  GemmProf* pr = prof_begin(d.b_kmajor ? 1 : 0, 2.0 * d.M * d.N * d.K, stream);
+  if (d.b_kmajor) hipLaunchKernelGGL(gemm_wsk_kernel<1>, dim3(p.nblk), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL(gemm_wsk_kernel<0>, dim3(p.nblk), dim3(512), 0, stream, p);
+  prof_end(pr, stream);
+  DVAE_LAUNCH_CHECK();
+  if (d.partials) { d.partials->slab = nullptr; d.partials->splits = 1; d.partials->stride = 0; }
+  return DVAE_OK;
+}
+// opt-in (DVAE_WSK=1): alone it beats the 64 x 64 tiles by 10-13 % on the 4096-row backward products, inside the step it
+// LOSES (headline 9.38 vs 9.32 ms, same box): its one 75 KB workgroup per CU cannot share a CU with two of the side
+// stream's 50 KB GEMM workgroups, so it queues behind them where the small tiles slip in (profiles/r03_level_gemm.txt)
+int g_wsk = getenv("DVAE_WSK") ? 1 : 0;
+}  // namespace
+
 int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0) return DVAE_OK;
   DVAE_REQUIRE(d.K > 0, "gemm: K must be positive");
@@ -571,6 +707,12 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
       else if (t64 >= 512) half = true;
       else quarter = true;
     }
+  }
+  // 4096-row per-level products that would take 64 x 64 tiles: the in-workgroup split-K kernel (gemm_wsk_kernel)
+  if (g_x6 && g_wsk && quarter && g_force_tile == 0 && g_force_splits == 0 && !d.a_kmajor && !d.k_map && (d.K & 63) == 0 &&
+      d.K >= 512 && (d.N & 3) == 0) {
+    const long long t = (long long)cdiv(d.M, 128) * cdiv(d.N, 64);
+    if (t >= 224 && t <= 512) return launch_wsk(d, stream);
   }
 #define GEMM_PICK(AK, BKK)                                                                   \
   if (g_x6) {                                                                                \

@@ -101,7 +101,11 @@ int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_
 int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
              hipStream_t st);
 int k_relu_bwd_colsum(float* D, const float* Y, int ld, int rows, int W, float* out, float* part,
-                      size_t part_floats, hipStream_t st);   // D *= (Y > 0), out = column sums of D
+                      size_t part_floats, hipStream_t st);
+// out[W][32] = X[rows][W]^T . [onehot(row_type[row]) | 1 | 0 ..]: column sums per node type (C < 32 types, every row typed),
+// one streaming pass; the layout of the [W x 32] TN product it replaces
+int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, float* part,
+                   size_t part_floats, hipStream_t st);   // D *= (Y > 0), out = column sums of D
 
 // [B][N][W] API tensors <-> node-row tables
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st);

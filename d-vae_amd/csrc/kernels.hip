@@ -594,6 +594,64 @@ __global__ __launch_bounds__(256) void colsum_kernel(float* __restrict__ X, cons
   }
 }
 
+// Column sums per node TYPE: part[chunk][t][w] = sum over the chunk's rows r with row_type[r] == t of X[r][w].
+// This is the skinny product X^T . onehot(type) (the decoder's per-type gradient sums DTT = DA^T . XP, sched.h TypeShare)
+// done as what it is -- one streaming pass over X -- instead of a [W x 32] GEMM tile grid that walks X in 16 KB steps:
+// a block owns 64 columns x one row chunk (16 row lanes x 16 float4 columns, as colsum_kernel); every thread keeps one
+// float4 accumulator per type in LDS, in a slot of its own (no lane ever touches another lane's slot), the row lanes are
+// folded in a fixed order at the end.  Rows whose type is -1 (not one-hot) must not occur (the caller checks info[5]).
+__global__ __launch_bounds__(256) void typed_colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc, int W,
+                                                           const int* __restrict__ row_type, int C, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float4 tacc[];   // [C][256]
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + cx * 4;
+  const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+  for (int t = 0; t < C; ++t) tacc[t * 256 + threadIdx.x] = zero4();
+  if (col < W) {
+    int r = r0 + ry;
+    // two rows in flight per lane
+    for (; r + 16 < r1; r += 32) {
+      const int t0 = row_type[r], t1 = row_type[r + 16];
+      const float4 v0 = ld4(X + (size_t)r * ld + col), v1 = ld4(X + (size_t)(r + 16) * ld + col);
+      float4* a0 = tacc + t0 * 256 + threadIdx.x;
+      *a0 = add4(*a0, v0);
+      float4* a1 = tacc + t1 * 256 + threadIdx.x;
+      *a1 = add4(*a1, v1);
+    }
+    if (r < r1) {
+      float4* a0 = tacc + row_type[r] * 256 + threadIdx.x;
+      *a0 = add4(*a0, ld4(X + (size_t)r * ld + col));
+    }
+  }
+  __syncthreads();
+  // lane (ry, cx) folds the 16 row lanes of types ry, ry + 16 for its columns
+  if (col < W)
+    for (int t = ry; t < C; t += 16) {
+      float4 s = tacc[t * 256 + cx];
+#pragma unroll
+      for (int k = 1; k < 16; ++k) s = add4(s, tacc[t * 256 + k * 16 + cx]);
+      st4(part + ((size_t)blockIdx.y * C + t) * W + col, s);
+    }
+}
+
+// out[w][c] = sum over chunks of part[chunk][c][w] (c < C), out[w][C] = the sum over all types (every row has exactly
+// one type: the column of ones of XP), the other columns of the 32 are zero
+__global__ void typed_colsum_final_kernel(const float* __restrict__ part, int nch, int C, int W, float* __restrict__ out) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  float tot = 0.f;
+  for (int c = 0; c < 32; ++c) {
+    float s = 0.f;
+    if (c < C) {
+      for (int k = 0; k < nch; ++k) s += part[((size_t)k * C + c) * W + w];
+      tot += s;
+    } else if (c == C) {
+      s = tot;
+    }
+    out[(size_t)w * 32 + c] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // glue
 // ---------------------------------------------------------------------------
@@ -1462,6 +1520,39 @@ int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, s
 int k_relu_bwd_colsum(float* D, const float* Y, int ld, int rows, int W, float* out, float* part,
                       size_t part_floats, hipStream_t st) {
   return colsum_launch(D, Y, ld, rows, W, out, part, part_floats, st);
+}
+
+// out[W][32] = X[rows][W]^T . [onehot(row_type) | 1 | 0..]  (the layout of the TN product it replaces); C < 32 types
+int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, float* part,
+                   size_t part_floats, hipStream_t st) {
+  DVAE_REQUIRE((W & 3) == 0 && (ld & 3) == 0 && C >= 1 && C < 32, "typed_colsum: widths must be multiples of 4, 1 <= C < 32");
+  if (rows <= 0) {
+    DVAE_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)W * 32 * 4, st));
+    return DVAE_OK;
+  }
+  const int gx = cdiv(W, 64);
+  int nch = std::max(1, std::min(cdiv(2048, gx), cdiv(rows, 128)));
+  nch = (int)std::max<size_t>(1, std::min<size_t>(nch, part_floats / ((size_t)W * C)));
+  DVAE_REQUIRE(part_floats >= (size_t)W * C, "typed_colsum: scratch too small");
+  const int rpc = std::max(1, cdiv(rows, nch));
+  nch = std::max(1, cdiv(rows, rpc));
+  const size_t lds = (size_t)C * 256 * sizeof(float4);
+  if (lds > 64 * 1024) {   // more than 64 KB of LDS is opt-in (17 or more node types)
+    static std::once_flag big_lds[16];
+    int dev = 0;
+    DVAE_CHECK_HIP(hipGetDevice(&dev));
+    hipError_t err = hipSuccess;
+    std::call_once(big_lds[dev & 15], [&] {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(typed_colsum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                31 * 256 * (int)sizeof(float4));
+    });
+    DVAE_CHECK_HIP(err);
+  }
+  hipLaunchKernelGGL(typed_colsum_kernel, dim3(gx, nch), dim3(256), lds, st, X, ld, rows, rpc, W, row_type, C, part);
+  DVAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 256)), dim3(256), 0, st, part, nch, C, W, out);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
 }
 
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st) {

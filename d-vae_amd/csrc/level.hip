@@ -14,6 +14,8 @@
 // Same MFMA (v_mfma_f32_32x32x2_f32) and the same gate formulas as gemm.hip +
 // kernels.hip; the fp32 summation order differs only where the plain GEMM splits K.
 #include "kernels.h"
+#include <mutex>
+
 #include "x6.h"
 
 namespace {
@@ -500,14 +502,16 @@ template <int G> __device__ __forceinline__ void small_epilogue(const GruEpi& e,
 template <int G> __device__ __forceinline__ void small_epilogue(const GmEpi& e, int HP, const GmRow& rw, int col, const float4* v) { epilogue(e, HP, rw, col, v); }
 template <int G> __device__ __forceinline__ void small_epilogue(const PlainEpi& e, int HP, const PlainRow& rw, int col, const float4* v) { epilogue_plain<G>(e, HP, rw, col, v); }
 
-template <int G, class Epi, int BKM>
-__global__ __launch_bounds__(256) void small_kernel(LevelCore p, Epi e) {
+// NW: waves per workgroup = ways the reduction is split (4, or 8: half as many sequential k-tiles per wave -- the kernel
+// runs one workgroup per CU at these sizes, i.e. one or two waves per SIMD, and is bound by that chain's latency)
+template <int G, class Epi, int BKM, int NW>
+__global__ __launch_bounds__(NW * 64) void small_kernel(LevelCore p, Epi e) {
   constexpr int A_FL = 32 * SLD;
   constexpr int B_FL = BKM ? G * SBK * SKN : G * 32 * SLD;
   constexpr int STAGE = A_FL + B_FL;                 // per wave
   constexpr int RED = G * 16 * 64;                   // per wave
-  constexpr int LDS_FL = (4 * STAGE > 4 * RED) ? 4 * STAGE : 4 * RED;
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FL];
+  constexpr int LDS_FL = (STAGE > RED ? STAGE : RED) * NW;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.prio) __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = blockIdx.x;
@@ -556,13 +560,13 @@ __global__ __launch_bounds__(256) void small_kernel(LevelCore p, Epi e) {
   };
   int t = wave;
   if (t < ntiles) load(t);
-  for (; t < ntiles; t += 4) {
+  for (; t < ntiles; t += NW) {
     // registers -> this wave's staging tiles (the previous tile's fragments are consumed: same wave, in order)
 #pragma unroll
     for (int i = 0; i < 2; ++i) st4(As + sa[i], va[i]);
 #pragma unroll
     for (int i = 0; i < 2 * G; ++i) st4(Bs + sb[i], vb[i]);
-    if (t + 4 < ntiles) load(t + 4);
+    if (t + NW < ntiles) load(t + NW);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(256) void small_kernel(LevelCore p, Epi e) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  // the four partial accumulators meet in LDS (over the staging area): red[wave][reg][lane]
+  // the NW partial accumulators meet in LDS (over the staging area): red[wave][reg][lane]
   __syncthreads();
   float* red = lds;
 #pragma unroll
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(256) void small_kernel(LevelCore p, Epi e) {
   // wave q finishes register group q of every gate: row m0 + (lane & 31), columns n0 + 8q + 4*(lane>>5) + 0..3
   const int q = wave;
   const int m = m0 + (lane & 31);
-  if (m >= p.M) return;
+  if (m >= p.M || q >= 4) return;     // the first four waves finish one register group each
   float4 v[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -609,8 +613,10 @@ __global__ __launch_bounds__(256) void small_kernel(LevelCore p, Epi e) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int r = g * 16 + 4 * q + c;
-      s[c] = ((red[(0 * G * 16 + r) * 64 + lane] + red[(1 * G * 16 + r) * 64 + lane]) +
-              red[(2 * G * 16 + r) * 64 + lane]) + red[(3 * G * 16 + r) * 64 + lane];
+      float acc_s = red[r * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) acc_s += red[(w * G * 16 + r) * 64 + lane];   // fixed order: wave 0, 1, ..
+      s[c] = acc_s;
     }
     v[g] = make_float4(s[0], s[1], s[2], s[3]);
   }
@@ -640,13 +646,43 @@ int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
   return DVAE_OK;
 }
 
+constexpr int small_lds_bytes(int G, int BKM, int NW) {
+  const int stage = 32 * SLD + (BKM ? G * SBK * SKN : G * 32 * SLD), red = G * 16 * 64;
+  return (stage > red ? stage : red) * NW * 4;
+}
+
+// waves per workgroup of the small-level kernels: 4 (default) or 8 (DVAE_SMALL_WAVES=8: half as many k-tiles per wave;
+// measured neutral -- B=512 2.33 vs 2.32 ms, B=32 1.62 vs 1.61, same box -- the step is not bound by these kernels' inner loops)
+static int g_small_waves = getenv("DVAE_SMALL_WAVES") ? atoi(getenv("DVAE_SMALL_WAVES")) : 4;
+
+template <int G, class Epi, int BKM, int NW>
+int launch_small_nw(const LevelCore& c, const Epi& e, hipStream_t st) {
+  constexpr int LDSB = small_lds_bytes(G, BKM, NW);
+  if (LDSB > 64 * 1024) {   // more than 64 KB of LDS is opt-in, once per device
+    static std::once_flag big_lds[16];
+    int dev = 0;
+    DVAE_CHECK_HIP(hipGetDevice(&dev));
+    hipError_t err = hipSuccess;
+    std::call_once(big_lds[dev & 15], [&] {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(small_kernel<G, Epi, BKM, NW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    });
+    DVAE_CHECK_HIP(err);
+  }
+  hipLaunchKernelGGL((small_kernel<G, Epi, BKM, NW>), dim3(c.nblk), dim3(NW * 64), LDSB, st, c, e);
+  return DVAE_OK;
+}
+
 template <int G, class Epi, int BKM>
 int launch_small(LevelCore c, const Epi& e, hipStream_t st) {
   c.tiles_n = c.HP / 32;
   c.nblk = cdiv(c.M, 32) * c.tiles_n;
   void* pr = gemm_prof_begin(2.0 * c.M * G * c.HP * (double)c.K, st);
-  hipLaunchKernelGGL((small_kernel<G, Epi, BKM>), dim3(c.nblk), dim3(256), 0, st, c, e);
+  // eight waves only where every wave still gets two or more k-tiles
+  const int rc = (g_small_waves == 8 && c.K / SBK >= 16) ? launch_small_nw<G, Epi, BKM, 8>(c, e, st)
+                                                          : launch_small_nw<G, Epi, BKM, 4>(c, e, st);
   gemm_prof_end(pr, st);
+  DVAE_TRY(rc);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }

@@ -240,6 +240,13 @@ struct XA : XTile<0, ROWS> {
     return XTile<0, ROWS>::frag(reinterpret_cast<const float*>(lds), p, rbase, ks, lane);
   }
 };
+template <int BKM, int ROWS>
+struct XB : XTile<BKM, ROWS> {
+  static constexpr int LDS_BYTES = XTile<BKM, ROWS>::LDS_FLOATS * 4;
+  static __device__ __forceinline__ bf16x8 frag(const char* lds, int p, int rbase, int ks, int lane) {
+    return XTile<BKM, ROWS>::frag(reinterpret_cast<const float*>(lds), p, rbase, ks, lane);
+  }
+};
 struct PH { const float* A; int lda; };
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void x6p_v3(P p, PH h) {
@@ -276,7 +283,86 @@ __global__ __launch_bounds__(256, 2) void x6p_v3(P p, PH h) {
   epilogue<TM, TN>(acc, p, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
+// ---------------- v4: in-workgroup split-K ("wsk"): fp32 operands split in the loop as in-tree; BM x BN tile, 512 threads =
+// two groups of four waves, group g takes the k-tiles g, g+2, .. with its own staging area; the two partial tiles meet in LDS ----
+template <int BM, int BN, int WM, int WN, int BKM>
+__global__ __launch_bounds__(512, 1) void x6_wsk(P p, PH h, const float* Bf, int ldb) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN == 4, "four waves per group");
+  using TA = XA<BM>;
+  using TB = XB<BKM, BN>;
+  constexpr int GROUP = TA::LDS_BYTES + TB::LDS_BYTES;
+  constexpr int REDB = BM * BN * 4;
+  constexpr int LDSB = 2 * GROUP > REDB ? 2 * GROUP : REDB;
+  __shared__ __attribute__((aligned(16))) char lds[LDSB];
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap(blockIdx.x, p.nblk);
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  char* As = lds + grp * GROUP;
+  char* Bs = As + TA::LDS_BYTES;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  TA ta; TB tb;
+  ta.rows_init(h.lda, m0, p.M, nullptr, tid);
+  tb.rows_init(ldb, n0, p.N, nullptr, tid);
+  const int nt = p.K / 64;     // k-tile pairs (K % 64 == 0 in the lab)
+  ta.template load<false>(h.A, h.lda, m0, p.M, grp * 32, p.K, tid);
+  tb.template load<false>(Bf, ldb, n0, p.N, grp * 32, p.K, tid);
+  ta.store(reinterpret_cast<float*>(As), tid); tb.store(reinterpret_cast<float*>(Bs), tid);
+  __syncthreads();
+  for (int t = 0; t + 1 < nt; ++t) {
+    ta.template load<false>(h.A, h.lda, m0, p.M, (t + 1) * 64 + grp * 32, p.K, tid);
+    tb.template load<false>(Bf, ldb, n0, p.N, (t + 1) * 64 + grp * 32, p.K, tid);
+    mma_tile<TM, TN, TA, TB>(acc, As, Bs, wm * (BM / WM), wn * (BN / WN), lane);
+    __syncthreads();
+    ta.store(reinterpret_cast<float*>(As), tid); tb.store(reinterpret_cast<float*>(Bs), tid);
+    __syncthreads();
+  }
+  mma_tile<TM, TN, TA, TB>(acc, As, Bs, wm * (BM / WM), wn * (BN / WN), lane);
+  __syncthreads();
+  // group 1 parks its partial tile in LDS ([wave][i][j][reg][lane]), group 0 adds it and stores
+  float* red = reinterpret_cast<float*>(lds);
+  if (grp == 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] += red[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane];
+  epilogue<TM, TN>(acc, p, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+}
+
 }  // namespace
+
+extern "C" int x6_wsk_gemm(int variant, const float* A, int lda, const float* B, int ldb, int b_kmajor, float* C, int M, int N, int K, void* stream) {
+  P p; p.A = nullptr; p.B = nullptr; p.C = C; p.M = M; p.N = N; p.K = K; p.ldc = N;
+  PH h; h.A = A; h.lda = lda;
+  hipStream_t st = (hipStream_t)stream;
+  auto grid = [&](int BM, int BN) { p.tiles_n = (N + BN - 1) / BN; p.nblk = ((M + BM - 1) / BM) * p.tiles_n; return dim3(p.nblk); };
+  if (variant == 0 && !b_kmajor) { dim3 g = grid(128, 64); hipLaunchKernelGGL((x6_wsk<128, 64, 2, 2, 0>), g, dim3(512), 0, st, p, h, B, ldb); }
+  else if (variant == 0) { dim3 g = grid(128, 64); hipLaunchKernelGGL((x6_wsk<128, 64, 2, 2, 1>), g, dim3(512), 0, st, p, h, B, ldb); }
+  else if (variant == 1 && !b_kmajor) { dim3 g = grid(64, 128); hipLaunchKernelGGL((x6_wsk<64, 128, 1, 4, 0>), g, dim3(512), 0, st, p, h, B, ldb); }
+  else if (variant == 1) { dim3 g = grid(64, 128); hipLaunchKernelGGL((x6_wsk<64, 128, 1, 4, 1>), g, dim3(512), 0, st, p, h, B, ldb); }
+  else if (variant == 2 && !b_kmajor) { dim3 g = grid(128, 128); hipLaunchKernelGGL((x6_wsk<128, 128, 2, 2, 0>), g, dim3(512), 0, st, p, h, B, ldb); }
+  else if (variant == 2) { dim3 g = grid(128, 128); hipLaunchKernelGGL((x6_wsk<128, 128, 2, 2, 1>), g, dim3(512), 0, st, p, h, B, ldb); }
+  else return -1;
+  return (int)hipGetLastError();
+}
 
 extern "C" int x6p_gemm_hybrid(int variant, const float* A, int lda, const void* B3, float* C, int M, int N, int K, void* stream) {
   P p; p.A = nullptr; p.B = (const uint4*)B3; p.C = C; p.M = M; p.N = N; p.K = K; p.ldc = N;

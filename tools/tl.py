@@ -10,7 +10,7 @@ starts = [i for i, r in enumerate(rows) if 'sched_levels' in r['Kernel_Name']]
 a, b = starts[-3], starts[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 def short(n):
-    n = re.sub(r'void \(anonymous namespace\)::', '', n)
+    n = n.replace('void ', '').replace('(anonymous namespace)::', '')
     n = re.sub(r'\(.*', '', n)
     return n[:48]
 print('step length %.1f us' % ((int(rows[b]['Start_Timestamp']) - t0) / 1e3))
