@@ -635,21 +635,21 @@ __global__ __launch_bounds__(256) void typed_colsum_kernel(const float* __restri
 }
 
 // out[w][c] = sum over chunks of part[chunk][c][w] (c < C), out[w][C] = the sum over all types (every row has exactly
-// one type: the column of ones of XP), the other columns of the 32 are zero
+// one type: the column of ones of XP), the other columns of the 32 are zero.  blockIdx.y = c; chunks summed in order.
 __global__ void typed_colsum_final_kernel(const float* __restrict__ part, int nch, int C, int W, float* __restrict__ out) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
   if (w >= W) return;
-  float tot = 0.f;
-  for (int c = 0; c < 32; ++c) {
-    float s = 0.f;
-    if (c < C) {
-      for (int k = 0; k < nch; ++k) s += part[((size_t)k * C + c) * W + w];
-      tot += s;
-    } else if (c == C) {
-      s = tot;
+  float s = 0.f;
+  if (c < C) {
+    for (int k = 0; k < nch; ++k) s += part[((size_t)k * C + c) * W + w];
+  } else if (c == C) {
+    for (int t = 0; t < C; ++t) {
+      float st = 0.f;
+      for (int k = 0; k < nch; ++k) st += part[((size_t)k * C + t) * W + w];
+      s += st;
     }
-    out[(size_t)w * 32 + c] = s;
   }
+  out[(size_t)w * 32 + c] = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -1550,7 +1550,7 @@ int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type,
   }
   hipLaunchKernelGGL(typed_colsum_kernel, dim3(gx, nch), dim3(256), lds, st, X, ld, rows, rpc, W, row_type, C, part);
   DVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 256)), dim3(256), 0, st, part, nch, C, W, out);
+  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 256), 32), dim3(256), 0, st, part, nch, C, W, out);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
