@@ -635,21 +635,22 @@ __global__ __launch_bounds__(256) void typed_colsum_kernel(const float* __restri
 }
 
 // out[w][c] = sum over chunks of part[chunk][c][w] (c < C), out[w][C] = the sum over all types (every row has exactly
-// one type: the column of ones of XP), the other columns of the 32 are zero.  blockIdx.y = c; chunks summed in order.
-__global__ void typed_colsum_final_kernel(const float* __restrict__ part, int nch, int C, int W, float* __restrict__ out) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-  if (w >= W) return;
+// one type: the column of ones of XP), the other columns of the 32 are zero.  A block finishes 8 columns w x 32 entries:
+// thread (wl, c) sums its chunks in order, the totals meet in LDS, and the block writes 1 KB of `out` contiguously.
+__global__ __launch_bounds__(256) void typed_colsum_final_kernel(const float* __restrict__ part, int nch, int C, int W,
+                                                                 float* __restrict__ out) {
+  __shared__ float sh[8][33];
+  const int c = threadIdx.x & 31, wl = threadIdx.x >> 5;
+  const int w = blockIdx.x * 8 + wl;
   float s = 0.f;
-  if (c < C) {
+  if (c < C && w < W)
     for (int k = 0; k < nch; ++k) s += part[((size_t)k * C + c) * W + w];
-  } else if (c == C) {
-    for (int t = 0; t < C; ++t) {
-      float st = 0.f;
-      for (int k = 0; k < nch; ++k) st += part[((size_t)k * C + t) * W + w];
-      s += st;
-    }
+  sh[wl][c] = s;
+  __syncthreads();
+  if (c == C) {
+    for (int t = 0; t < C; ++t) s += sh[wl][t];
   }
-  out[(size_t)w * 32 + c] = s;
+  if (w < W) out[(size_t)w * 32 + c] = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -1550,7 +1551,7 @@ int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type,
   }
   hipLaunchKernelGGL(typed_colsum_kernel, dim3(gx, nch), dim3(256), lds, st, X, ld, rows, rpc, W, row_type, C, part);
   DVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 256), 32), dim3(256), 0, st, part, nch, C, W, out);
+  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 8)), dim3(256), 0, st, part, nch, C, W, out);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
