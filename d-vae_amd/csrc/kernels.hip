@@ -1556,6 +1556,14 @@ int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type,
   return DVAE_OK;
 }
 
+// unit-test surface of k_typed_colsum (include/dvae_hip.h)
+extern "C" int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out32,
+                                 float* part, size_t part_floats, void* stream) {
+  DVAE_REQUIRE(X && row_type && out32 && part, "typed_colsum: null pointer");
+  DVAE_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)part & 15) == 0, "typed_colsum: operands must be 16-byte aligned");
+  return k_typed_colsum(X, ld, rows, W, row_type, C, out32, part, part_floats, (hipStream_t)stream);
+}
+
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
   hipLaunchKernelGGL(rows_to_dense_kernel, grid_for((long long)R * W), dim3(256), 0, st, S, R, T, ld, out, N, W);

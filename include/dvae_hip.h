@@ -281,6 +281,13 @@ int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share);
  * reduction split over the waves of a workgroup, gates fused into the forward products; default 1024, environment
  * DVAE_SMALL_ROWS); 0 = never.  Same formulas either way (fp32 summation order differs). */
 int dvae_small_rows_tune(int rows);
+/* Per-type column sums (unit-test surface): out32[w][c] = sum over the rows of type c of X[row][w] for c < C, out32[w][C] =
+ * the sum over all rows, the other entries of the 32 zero -- the product X^T . [onehot(type) | 1] of the decoder's per-type
+ * gradient sums (the backward of Decoder.forward's k = 0 states, dvae_model.py:203-207, shared by node type) as one
+ * streaming pass.  row_type[rows] in [0, C), C < 32; W, ld multiples of 4; part: scratch of at least W * C floats (more
+ * scratch = more row chunks in flight). */
+int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out32,
+                      float* part, size_t part_floats, void* stream);
 /* test surface (no counterpart in the reference): which kernels score add_edge's pairs (dvae_model.py:210-220) for
  * graphs of up to N nodes at add_edge width EHP (dvae_dims.EHP).  Bits: 1 forward on the LDS-sliced scorer, 2 with more
  * than one window of candidate rows, 4 backward fused per graph (accumulators on chip), 8 backward windowed one-pass;

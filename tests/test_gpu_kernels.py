@@ -399,3 +399,27 @@ def test_small_gemm(cuda, M, G, HP, K, km, acc):
         ref = ref + C0[:M].double()
     assert torch.allclose(C[:M].double(), ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
     assert torch.equal(C[M:], C0[M:])
+
+
+@pytest.mark.parametrize("rows,W,C,ld_pad", [(28672, 2048, 8, 0), (1000, 1024, 10, 64), (37, 64, 1, 0), (5000, 3072, 31, 0),
+                                             (0, 256, 8, 0), (513, 2048, 17, 0)])
+def test_typed_colsum(cuda, rows, W, C, ld_pad):
+    """Per-type column sums (the decoder's DTT = DA^T . [onehot(type) | 1]) against torch: every type count incl. the
+    LDS opt-in sizes (17+ types), a padded leading dimension, a single row chunk, no rows at all."""
+    from dvae_amd import engine as E
+    from dvae_amd._lib import load
+    lib = load()
+    torch.manual_seed(7)
+    ld = W + ld_pad
+    X = torch.randn(max(rows, 1), ld, device=cuda)
+    t = torch.randint(0, C, (max(rows, 1),), device=cuda, dtype=torch.int32)
+    out = torch.full((W, 32), float("nan"), device=cuda)
+    part = torch.empty(8 << 20, device=cuda)
+    E.check(lib.dvae_typed_colsum(E._ptr(X), ld, rows, W, E._ptr(t), C, E._ptr(out), E._ptr(part), part.numel(), E._stream()))
+    torch.cuda.synchronize()
+    onehot = torch.zeros(max(rows, 1), 32, device=cuda, dtype=torch.float64)
+    onehot[torch.arange(max(rows, 1), device=cuda), t.long()] = 1.0
+    onehot[:, C] = 1.0
+    ref = X[:rows, :W].double().t() @ onehot[:rows]
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * max(rows, 1) ** 0.5)
+    assert torch.equal(out[:, C + 1:], torch.zeros_like(out[:, C + 1:]))
