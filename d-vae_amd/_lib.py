@@ -83,6 +83,7 @@ SIGNATURES = {
     "dvae_gemm_dbg": (c_int, [c_int]),
     "dvae_level_tune": (c_int, [c_int, c_int, c_int]),
     "dvae_small_rows_tune": (c_int, [c_int]),
+    "dvae_enc_merge_tune": (c_int, [c_int]),
     "dvae_pair_path": (c_int, [c_int, c_int]),
     "dvae_typed_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dvae_wgrad_split_tune": (c_int, [ctypes.c_double, c_int]),
@@ -186,4 +187,9 @@ def make_svae_dims(B, T, C, N, H, Z, bidir):
 
 
 def sched_info_ints(N):
+    return 8 + 6 * (N + 1) + 4
+
+
+def sched_merge_at(N):
+    """First int of the shared-encoder-row summary (include/dvae_hip.h)."""
     return 8 + 4 * (N + 1)

@@ -237,6 +237,7 @@ struct Levels {
   const int* ls;   // node-row level starts [nlev+1]
   const int* es;   // edge-space level starts (forward only)
   const int* as;   // the same in scored edge rows (SchedView::a_rows)
+  const int* cs = nullptr;   // shared encoder rows only: successor links before each level start
   int N;
   // scored edge rows before edge-space position e, which must be a level start
   // predecessor links of level L's nodes (exact in the forward direction, pro rata in the reverse one, whose
@@ -259,6 +260,16 @@ Levels levels_of(const dvae_dims& d, const int* info, int dir) {
   l.es = info + 8 + 2 * (d.N + 1);
   l.as = info + 8 + 3 * (d.N + 1);
   l.N = d.N;
+  return l;
+}
+
+// shared encoder rows (sched.h SchedView::enc): the encoder's forward-direction sweep on one row per distinct value
+bool enc_shared(const dvae_dims& d, const int* info) { return info[DVAE_SCHED_MERGE_AT(d.N)] == 1; }
+Levels levels_shared(const dvae_dims& d, const int* info, const Levels& lf) {
+  const int* mi = info + DVAE_SCHED_MERGE_AT(d.N);
+  Levels l = lf;          // same level count; es / as belong to prefix sweeps and are not read by a node sweep
+  l.R = mi[1]; l.E = mi[2]; l.ls = mi + 4; l.dir = 2;
+  l.cs = mi + 5 + d.N;
   return l;
 }
 
@@ -452,7 +463,14 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
     }
     {
       KernelProf kp(7, 8.0 * d.H * (lv.E + 2.0 * R), st);
-      DVAE_TRY(k_dgm_bwd(S, 0, R, b, HP, st));
+      if (lv.cs) {   // shared encoder rows: level by level, the first levels' long successor lists split over lanes
+        for (int L = 0; L < lv.nlev; ++L) {
+          const int ns = lv.ls[L], ne = lv.ls[L + 1];
+          DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st, ne > ns ? (double)(lv.cs[L + 1] - lv.cs[L]) / (ne - ns) : 0.0));
+        }
+      } else {
+        DVAE_TRY(k_dgm_bwd(S, 0, R, b, HP, st));
+      }
     }
     return DVAE_OK;
   }
@@ -483,7 +501,7 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
         }
       } else {
         KernelProf kp(7, 8.0 * d.H * (lv.level_edges(L + 1) + 2.0 * (ne - ns)), st);
-        DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st));
+        DVAE_TRY(k_dgm_bwd(S, ns, ne, b, HP, st, lv.cs && ne > ns ? (double)(lv.cs[L + 1] - lv.cs[L]) / (ne - ns) : 0.0));
       }
       if (ne - ns <= small_rows && !b.prefix) {
         // node sweeps: the gate/map input gradient lands on the rows whose GRU step comes next -- product and
@@ -640,8 +658,13 @@ extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* 
   const G g{w.sc[0].gemm_ws, st, 1};
   const int HP = d.HP, B = d.B;
 
+  // the forward-direction sweep runs on one row per distinct node value when the schedule has them
+  const bool shared = enc_shared(d, info);
+  const SchedDir& Sf = shared ? sv.enc : sv.dir[0];
+  const Levels lfs = shared ? levels_shared(d, info, lf) : lf;
+  if (shared) w.f.R = w.f.RH = lfs.R;   // the tables were carved for one row per node; the sweep's rows end here
   SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
-  DVAE_TRY(sweep_fwd(d, sv.dir[0], lf, w.f, wf, x, nullptr, g));
+  DVAE_TRY(sweep_fwd(d, Sf, lfs, w.f, wf, x, nullptr, g));
   if (d.bidir) {
     const Levels lr = levels_of(d, info, 1);
     SweepW wr{gru_at(P + L.gru_b, HP, d.C), P + L.gm_b};
@@ -649,21 +672,23 @@ extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* 
     // lin01 chain, applied once per reverse-sweep step (dvae_model.py:119): hv_{t+1} = W01.[hv_t ; hb] + b01.  The hb
     // half does not depend on the chain: Q = W01b.hb + b01 for every reverse-sweep node row in ONE product, and a step is
     // one launch (hv_t.W01a^T + Q's row for the graphs that still have a step t, hv_t for the others)
-    DVAE_TRY(k_take_last_fwd(sv.dir[0], sizes, B, d.N, w.f.Hn, w.HVC, HP, st));
+    DVAE_TRY(k_take_last_fwd(Sf, sizes, B, d.N, w.f.Hn, w.HVC, HP, st));
     DVAE_TRY(g.nt(w.r.Hn, HP, P + L.W01 + HP, 2 * HP, w.Q, HP, lr.R, HP, HP, P + L.b01));
     for (int t = 0; t < d.N; ++t) {
       float* hv_t = w.HVC + (size_t)t * B * HP;
       DVAE_TRY(k_chain_fwd_step(sv.dir[1], sizes, B, d.N, t, hv_t, P + L.W01, 2 * HP, w.Q, hv_t + (size_t)B * HP, HP, g.prio, st));
     }
   } else {
-    DVAE_TRY(k_take_last_fwd(sv.dir[0], sizes, B, d.N, w.f.Hn, w.HVF, HP, st));
+    DVAE_TRY(k_take_last_fwd(Sf, sizes, B, d.N, w.f.Hn, w.HVF, HP, st));
   }
   // mu | logvar heads (dvae_model.py:121-122)
   DVAE_TRY(g.nt(w.HVF, HP, P + L.Wml, HP, w.ML, 2 * d.ZP, B, 2 * d.ZP, HP, P + L.bml));
   if (hv) DVAE_TRY(k_unpad_rows(w.HVF, HP, B, d.H, hv, st));
   if (mu) DVAE_TRY(k_unpad_rows(w.ML, 2 * d.ZP, B, d.Z, mu, st));
   if (logvar) DVAE_TRY(k_unpad_rows(w.ML + d.ZP, 2 * d.ZP, B, d.Z, logvar, st));
-  if (states) {
+  if (states && shared) {
+    DVAE_TRY(k_nodes_to_dense(Sf, B, d.N, w.f.Hn, HP, states, d.H, st));
+  } else if (states) {
     DVAE_CHECK_HIP(hipMemsetAsync(states, 0, (size_t)B * d.N * d.H * 4, st));
     DVAE_TRY(k_rows_to_dense(sv.dir[0], lf.R, w.f.Hn, HP, states, d.N, d.H, st));
   }
@@ -704,6 +729,11 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
 
   DVAE_TRY(k_zero(w.f.DH, (size_t)std::max(lf.R, 1) * HP * 4, st));
   SweepW wf{gru_at(P + L.gru_f, HP, d.C), P + L.gm_f};
+  // shared encoder rows: a row's gradient is the sum over its consumers, i.e. over every node it stands for
+  const bool shared = enc_shared(d, info);
+  const SchedDir& Sf = shared ? sv.enc : sv.dir[0];
+  const Levels lfs = shared ? levels_shared(d, info, lf) : lf;
+  if (shared) w.f.R = w.f.RH = lfs.R;
   if (d.bidir) {
     const Levels lr = levels_of(d, info, 1);
     SweepW wr{gru_at(P + L.gru_b, HP, d.C), P + L.gm_b};
@@ -718,7 +748,7 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
       DVAE_TRY(k_chain_bwd_step(sv.dir[1], sizes, B, d.N, t, d_t + (size_t)B * HP, P + L.W01, 2 * HP, d_t, w.DQ,
                                 w.DA + (size_t)t * B * HP, HP, g.prio, st));
     }
-    DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVC, w.f.DH, HP, st));
+    DVAE_TRY(k_take_last_bwd(Sf, sizes, B, d.N, w.DHVC, w.f.DH, HP, st));
     // dL/dhb = DQ.W01b into the reverse sweep's DH (zero so far); weight gradients on the side stream:
     // dW01a = DA^T.hv_t over all N*B chain rows, dW01b = DQ^T.hb over the reverse-sweep rows, db01 = column sums of DQ
     DVAE_TRY(g.nn(w.DQ, HP, P + L.W01 + HP, 2 * HP, w.r.DH, HP, lr.R, HP, HP, 1));
@@ -729,9 +759,9 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     DVAE_TRY(sweep_bwd_wgrad(d, sv.dir[1], lr, w.r, wr, x,
                              WgradOut{Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b}, false, g, gs, ev));
   } else {
-    DVAE_TRY(k_take_last_bwd(sv.dir[0], sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
+    DVAE_TRY(k_take_last_bwd(Sf, sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
-  DVAE_TRY(sweep_bwd_wgrad(d, sv.dir[0], lf, w.f, wf, x,
+  DVAE_TRY(sweep_bwd_wgrad(d, Sf, lfs, w.f, wf, x,
                            WgradOut{Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f}, false, g, gs, ev));
   return DVAE_OK;
 }

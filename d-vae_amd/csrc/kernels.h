@@ -89,7 +89,9 @@ int k_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmajor,
 int k_level_agg_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
                         const GruW& w, int HP, int prio, hipStream_t st);
 // with_gm_grad=0 (mod bn): only gathers dGM into GMP[:, :HP] scaled for the weight grads
-int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
+// links_per_row: average successor-list length of the rows, when the caller knows it (long lists take a kernel that
+// splits each list over lanes); 0 = unknown
+int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st, double links_per_row = 0.0);
 // parts: the gate/map input gradient of node rows [parts_row0, ..) as split-K slabs (GemmDesc::partials),
 // still to be added to the table that product accumulates into (DH, or DHn for prefix sweeps)
 int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hipStream_t st,
@@ -109,6 +111,9 @@ int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type,
 
 // [B][N][W] API tensors <-> node-row tables
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st);
+// the same through node2row: out[b][i][:W] = T[row of node (b,i)] (0 for absent nodes); for schedules whose rows
+// stand for several nodes (SchedView::enc)
+int k_nodes_to_dense(const SchedDir& S, int B, int N, const float* T, int ld, float* out, int W, hipStream_t st);
 int k_dense_to_rows(const SchedDir& S, int R, const float* in, int N, int W, float* T, int ld, hipStream_t st);
 
 // encoder glue: state of each graph's last node (dvae_model.py:121 uses the loop's final hv)

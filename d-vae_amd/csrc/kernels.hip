@@ -374,6 +374,32 @@ __global__ void dgm_bwd_kernel(SchedDir S, int ns, int ne, int prefix, const flo
   }
 }
 
+// The same for rows with LONG successor lists -- shared encoder rows of the first levels (sched.h
+// SchedView::enc: a value row of level 0 feeds thousands of rows): SL lanes walk a row's list side by side
+// (lane s takes links s, s + SL, ...), their partial sums are folded through LDS in lane order.  One block =
+// one row x 256/SL float4 columns.
+template <int SL>
+__global__ __launch_bounds__(256) void dgm_bwd_wide_kernel(SchedDir S, int ns, int ne, const float* __restrict__ DAGG,
+                                                           float* __restrict__ GMP, int HP) {
+  constexpr int CL = 256 / SL;
+  __shared__ float4 sh[SL][CL];
+  const int cl = threadIdx.x % CL, sl = threadIdx.x / CL;
+  const int chunks = HP / (4 * CL);
+  const int r = ns + blockIdx.x / chunks, j = ((blockIdx.x % chunks) * CL + cl) * 4;
+  float4 d = zero4();
+  const int e1 = S.csc_ptr[r + 1];
+  for (int e = S.csc_ptr[r] + sl; e < e1; e += SL) d = add4(d, ld4(DAGG + (size_t)S.csc_idx[e] * HP + j));
+  sh[sl][cl] = d;
+  __syncthreads();
+  if (sl != 0) return;
+  for (int k = 1; k < SL; ++k) d = add4(d, sh[k][cl]);
+  float* gp = GMP + (size_t)r * 2 * HP;
+  const float4 g = ld4(gp + j), m = ld4(gp + HP + j);
+  st4(gp + j, make_float4(d.x * m.x * g.x * (1.f - g.x), d.y * m.y * g.y * (1.f - g.y),
+                          d.z * m.z * g.z * (1.f - g.z), d.w * m.w * g.w * (1.f - g.w)));
+  st4(gp + HP + j, make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w));
+}
+
 // Prefix sweeps with one hidden product per node: for node u, over every consumer prefix row that
 // holds u, DGM[u] = sum of the direct gradients (DH after gru_bwd) and PG[u] = sum of dgh (GH after
 // gru_bwd).  dL/dGM[u] = DGM[u] + PG[u].Whh follows by a GEMM, then gm_bwd_apply.
@@ -662,6 +688,16 @@ __global__ void rows_to_dense_kernel(SchedDir S, int R, const float* __restrict_
   ITEM_LOOP(total) {
     const int r = (int)(it / W), c = (int)(it % W);
     out[((size_t)S.row_graph[r] * N + S.row_node[r]) * W + c] = T[(size_t)r * ld + c];
+  }
+}
+
+__global__ void nodes_to_dense_kernel(SchedDir S, int B, int N, const float* __restrict__ T, int ld,
+                                      float* __restrict__ out, int W) {
+  const long long total = (long long)B * N * W;
+  ITEM_LOOP(total) {
+    const int id = (int)(it / W), c = (int)(it % W);
+    const int r = S.node2row[id];
+    out[it] = r >= 0 ? T[(size_t)r * ld + c] : 0.f;
   }
 }
 
@@ -1462,8 +1498,19 @@ int k_gm_bn_fwd(const SchedDir& S, int R, const SweepBufs& b, const float* x, in
   return DVAE_OK;
 }
 
-int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st) {
+int k_dgm_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st, double links_per_row) {
   if (ne <= ns) return DVAE_OK;
+  // long successor lists (shared encoder rows): lanes side by side on a row's list; HP is a multiple of 64
+  if (!b.prefix && links_per_row > 6.0 && (long long)(ne - ns) * (HP / 16) < (1ll << 31)) {
+    if (links_per_row > 48.0)
+      hipLaunchKernelGGL(dgm_bwd_wide_kernel<64>, dim3((unsigned)((ne - ns) * (HP / 16))), dim3(256), 0, st, S, ns, ne, b.DH,
+                         b.GMP, HP);
+    else
+      hipLaunchKernelGGL(dgm_bwd_wide_kernel<16>, dim3((unsigned)((ne - ns) * (HP / 64))), dim3(256), 0, st, S, ns, ne, b.DH,
+                         b.GMP, HP);
+    DVAE_LAUNCH_CHECK();
+    return DVAE_OK;
+  }
   hipLaunchKernelGGL(dgm_bwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, ns, ne,
                      b.prefix, b.DH, b.GMP, HP);
   DVAE_LAUNCH_CHECK();
@@ -1562,6 +1609,13 @@ extern "C" int dvae_typed_colsum(const float* X, int ld, int rows, int W, const 
   DVAE_REQUIRE(X && row_type && out32 && part, "typed_colsum: null pointer");
   DVAE_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)part & 15) == 0, "typed_colsum: operands must be 16-byte aligned");
   return k_typed_colsum(X, ld, rows, W, row_type, C, out32, part, part_floats, (hipStream_t)stream);
+}
+
+int k_nodes_to_dense(const SchedDir& S, int B, int N, const float* T, int ld, float* out, int W, hipStream_t st) {
+  if (B <= 0 || N <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(nodes_to_dense_kernel, grid_for((long long)B * N * W), dim3(256), 0, st, S, B, N, T, ld, out, W);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
 }
 
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st) {

@@ -36,7 +36,26 @@ struct SchedView {
                       //      (the last pair of such a node, (i,0), is scored before edge 0 is added)
   int* a_skip;        // [EM] the other edge rows, ascending
   SchedDir dir[2];    // 0 forward, 1 reverse
+  // ---- encoder value numbering (dvae_sched_types, sched.hip "shared encoder rows") ----
+  // Two nodes of the batch with the same index, the same type and predecessor lists that hold the same
+  // VALUES have the same encoder state (dvae_model.py:63-87 computes it from nothing else), so the forward
+  // sweep of the encoder runs on one row per distinct value.  enc is dir[0] with those rows: node2row maps
+  // every node to its value's row, row_graph/row_node name the representative (lowest graph index), csr/csc
+  // are the links between value rows (csc lists ascending).  The last node of a graph is never shared (its row
+  // takes the graph's own gradient).  info[DVAE_SCHED_MERGE_AT(N)] = 1 when enc is valid.
+  SchedDir enc;
+  unsigned long long* vh;       // [2*RM] 128-bit value hash per node
+  unsigned long long* skey[2];  // [RM] sort keys in / out
+  int* sval[2];                 // [max(RM,EM)] sort values in / out
+  int* pkey[2];                 // [EM] (predecessor row, row) pairs: keys in / out
+  int* rep;                     // [RM] node id (b*N+i) of the representative of each node's value
+  int* gidx;                    // [RM+1] value group of each sorted position
+  int* gfirst;                  // [RM] first node id of each group
+  void* sort_tmp; size_t sort_tmp_bytes;
 };
+// first int of the shared-row summary in the schedule info: [0] valid, [1] rows, [2] links, [3] spare, [4..4+N] level
+// starts, [5+N..5+2N] successor links before each level start
+#define DVAE_SCHED_MERGE_AT(N) (8 + 4 * ((N) + 1))
 
 // Decoder prefix rows of node row r (k = 0..deg(r), k predecessors summed):
 //   prow(r,0) = r                       -- h_in = 0 (or h0 for node 0): no hidden GEMM

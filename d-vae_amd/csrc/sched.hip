@@ -5,7 +5,10 @@
 // 128-bit masks.
 #include "sched.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -56,6 +59,34 @@ SchedView carve(void* base, int B, int N, size_t* total) {
     } else {
       s.csc_prow = nullptr; s.csc_cnt = nullptr; s.prow_node = nullptr;
     }
+  }
+  {
+    SchedDir& s = v.enc;
+    s.level = v.dir[0].level;      // a value's level is the level of each of its nodes
+    s.node2row = c.take<int>(v.RM);
+    s.pos = c.take<int>((size_t)N * B + 1);
+    s.row_graph = c.take<int>(v.RM);
+    s.row_node = c.take<int>(v.RM);
+    s.csr_ptr = c.take<int>(v.RM + 1);
+    s.csc_ptr = c.take<int>(v.RM + 1);
+    s.csr_idx = c.take<int>(v.EM);
+    s.csc_idx = c.take<int>(v.EM);
+    s.csc_prow = nullptr; s.csc_cnt = nullptr; s.prow_node = nullptr;
+    const size_t m = (size_t)std::max(v.RM, v.EM);
+    v.vh = c.take<unsigned long long>((size_t)2 * v.RM);
+    v.skey[0] = c.take<unsigned long long>(v.RM);
+    v.skey[1] = c.take<unsigned long long>(v.RM);
+    v.sval[0] = c.take<int>(m);
+    v.sval[1] = c.take<int>(m);
+    v.pkey[0] = c.take<int>(v.EM);
+    v.pkey[1] = c.take<int>(v.EM);
+    v.rep = c.take<int>(v.RM);
+    v.gidx = c.take<int>((size_t)v.RM + 1);
+    v.gfirst = c.take<int>(v.RM);
+    // the radix sorts' scratch: a second copy of keys and values plus digit counters; dvae_sched_types asks the
+    // library what it needs and leaves the rows unshared if this does not cover it
+    v.sort_tmp_bytes = 16 * m + ((size_t)4 << 20);
+    v.sort_tmp = c.take<char>(v.sort_tmp_bytes);
   }
   if (total) *total = c.off;
   return v;
@@ -356,6 +387,7 @@ __global__ void sched_info_kernel(SchedView s, int want_rev) {
   for (int L = 0; L <= N; ++L) as[L] = s.a_pos[es[L]];
   info[5] = info[6] = 0;
   info[7] = s.err[3] == 0 ? 1 : 0;
+  info[DVAE_SCHED_MERGE_AT(N)] = 0;   // shared encoder rows: dvae_sched_types
 }
 
 // node type of every forward node row; err[1] counts rows whose encoding is not one-hot,
@@ -387,6 +419,275 @@ __global__ void sched_types_info_kernel(SchedView s) {
   }
 }
 
+
+// ===========================================================================
+// shared encoder rows (value numbering of the forward encoder sweep)
+// ===========================================================================
+// The state of node i (dvae_model.py:63-87) is a function of its type, its index (position one-hot of the
+// gate/map input, :71) and the states of its predecessors, summed in descending index order -- nothing else.
+// Nodes of different graphs that agree in all three hold the same state, and at ENAS sizes most nodes of the
+// first levels do (8 types: 8 / 64 / ~1000 distinct states among the 4096 nodes with index 0 / 1 / 2).  The
+// sweep therefore runs on one row per distinct VALUE; gradients reach a shared row from all its consumers, so
+// every sum the backward pass forms is the sum over the nodes the row stands for.
+//   1. a 128-bit hash of (index, type, hashes of the predecessors) per node, graph by graph;
+//   2. nodes sorted by hash (stable radix sort: equal hashes keep ascending node id) -> groups; the
+//      representative of a group is its first = lowest node id;
+//   3. every node is CHECKED against its representative: same index, type, predecessor index set, and the
+//      predecessors' representatives equal one by one -- by induction over the index the states are equal.
+//      A failed check (a hash collision) clears the valid flag: the batch runs unshared;
+//   4. value rows ordered by (level, graph, index) of the representative, CSR through node2row, and the
+//      successor lists by a stable sort of the (predecessor row, row) pairs.
+// The last node of a graph keeps a row of its own: it receives that graph's gradient (take_last).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)v, o), hi = __shfl_xor((unsigned)(v >> 32), o);
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void merge_hash_kernel(SchedView s) {
+  __shared__ unsigned long long h0[DVAE_MAX_N], h1[DVAE_MAX_N];
+  const int b = blockIdx.x, lane = threadIdx.x, N = s.N;
+  const SchedDir& S = s.dir[0];
+  const uint32_t* rb = s.rowbits + (size_t)b * N * DVAE_BITW;
+  int n = 0;
+  for (int i = 0; i < N; ++i) n += S.level[b * N + i] >= 0;   // nodes [0, n) are present (sched_levels_kernel)
+  for (int i = 0; i < n; ++i) {
+    unsigned long long a0 = 0, a1 = 0;
+    for (int u = lane; u < i; u += 64)
+      if (bit_of(rb + i * DVAE_BITW, u)) {
+        a0 += mix64(h0[u] ^ 0x6a09e667f3bcc908ull);
+        a1 += mix64(h1[u] + 0xbb67ae8584caa73bull);
+      }
+    a0 = wave_sum_u64(a0);
+    a1 = wave_sum_u64(a1);
+    if (lane == 0) {
+      const int t = s.row_type[S.node2row[b * N + i]];
+      const unsigned long long base = ((unsigned long long)(unsigned)i << 32) | (unsigned)(t + 1);
+      unsigned long long v0 = mix64(mix64(base) ^ a0), v1 = mix64(mix64(base + 0x3c6ef372fe94f82bull) + a1);
+      if (i == n - 1) {   // never shared
+        v0 = mix64(v0 ^ mix64(0xa54ff53a5f1d36f1ull + (unsigned)b));
+        v1 = mix64(v1 + mix64(0x510e527fade682d1ull ^ (unsigned)b));
+      }
+      h0[i] = v0;
+      h1[i] = v1;
+    }
+    __syncthreads();
+  }
+  for (int i = lane; i < N; i += 64) {
+    const int id = b * N + i;
+    s.vh[2 * (size_t)id] = i < n ? h0[i] : ~0ull;
+    s.vh[2 * (size_t)id + 1] = i < n ? h1[i] : ~0ull;
+    s.skey[0][id] = i < n ? h0[i] : ~0ull;   // absent nodes sort to the end
+    s.sval[0][id] = id;
+  }
+}
+
+__device__ __forceinline__ bool merge_boundary(const SchedView& s, int k) {
+  const int id = s.sval[1][k];
+  if (s.dir[0].level[id] < 0) return false;
+  if (k == 0) return true;
+  const int pv = s.sval[1][k - 1];
+  return s.vh[2 * (size_t)id] != s.vh[2 * (size_t)pv] || s.vh[2 * (size_t)id + 1] != s.vh[2 * (size_t)pv + 1] ||
+         s.dir[0].level[pv] < 0;
+}
+
+__global__ void merge_flags_kernel(SchedView s) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < s.RM; k += gridDim.x * blockDim.x)
+    s.gidx[k] = merge_boundary(s, k) ? 1 : 0;
+}
+
+// after the exclusive scan: a group's first position holds its index, the others index + 1
+__global__ void merge_first_kernel(SchedView s) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < s.RM; k += gridDim.x * blockDim.x)
+    if (merge_boundary(s, k)) s.gfirst[s.gidx[k]] = s.sval[1][k];
+}
+
+__global__ void merge_rep_kernel(SchedView s) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < s.RM; k += gridDim.x * blockDim.x) {
+    const int id = s.sval[1][k];
+    if (s.dir[0].level[id] < 0) { s.rep[id] = -1; continue; }
+    s.rep[id] = s.gfirst[merge_boundary(s, k) ? s.gidx[k] : s.gidx[k] - 1];
+  }
+}
+
+// the check of step 3; err[4] |= 1 on any disagreement
+__global__ void merge_check_kernel(SchedView s) {
+  const int N = s.N;
+  const SchedDir& S = s.dir[0];
+  for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < s.RM; id += gridDim.x * blockDim.x) {
+    if (S.level[id] < 0) continue;
+    const int r = s.rep[id];
+    const int b = id / N, i = id - b * N;
+    const bool last = i == N - 1 || S.level[id + 1] < 0;
+    bool ok = r >= 0 && r <= id && S.level[r] >= 0 && s.rep[r] == r;
+    if (ok && r != id) {
+      const int rb = r / N, ri = r - rb * N;
+      const bool rlast = ri == N - 1 || S.level[r + 1] < 0;
+      ok = !last && !rlast && ri == i && s.row_type[S.node2row[id]] == s.row_type[S.node2row[r]] &&
+           S.level[id] == S.level[r];
+      const uint32_t* pa = s.rowbits + (size_t)id * DVAE_BITW;
+      const uint32_t* pb = s.rowbits + (size_t)r * DVAE_BITW;
+      for (int w = 0; ok && w < DVAE_BITW; ++w) {
+        uint32_t m = pa[w];
+        ok = m == pb[w];
+        while (ok && m) {
+          const int u = w * 32 + __ffs(m) - 1;
+          m &= m - 1;
+          ok = s.rep[b * N + u] == s.rep[rb * N + u];
+        }
+      }
+    }
+    if (!ok) atomicOr(s.err + 4, 1);
+  }
+}
+
+// representatives per (level, graph), as sched_levels_kernel counts nodes
+__global__ __launch_bounds__(64) void merge_count_kernel(SchedView s) {
+  const int b = blockIdx.x, lane = threadIdx.x, N = s.N, B = s.B;
+  for (int L = lane; L < N; L += 64) {
+    int c = 0;
+    for (int i = 0; i < N; ++i) {
+      const int id = b * N + i;
+      c += (s.dir[0].level[id] == L && s.rep[id] == id);
+    }
+    s.enc.pos[(size_t)L * B + b] = c;
+  }
+}
+
+__global__ __launch_bounds__(64) void merge_assign_kernel(SchedView s) {
+  const int b = blockIdx.x, lane = threadIdx.x, N = s.N, B = s.B;
+  SchedDir& M = s.enc;
+  for (int i = lane; i < N; i += 64) {
+    const int id = b * N + i, L = s.dir[0].level[id];
+    int row = -1;
+    if (L >= 0 && s.rep[id] == id) {
+      int rank = 0;
+      for (int j = 0; j < i; ++j) rank += (s.dir[0].level[b * N + j] == L && s.rep[b * N + j] == b * N + j);
+      row = M.pos[(size_t)L * B + b] + rank;
+      M.row_graph[row] = b;
+      M.row_node[row] = i;
+      int deg = 0;
+#pragma unroll
+      for (int w = 0; w < DVAE_BITW; ++w) deg += __popc(s.rowbits[(size_t)id * DVAE_BITW + w]);
+      M.csr_ptr[row] = deg;   // scanned in place afterwards
+    }
+    M.node2row[id] = row;
+  }
+}
+
+__global__ void merge_map_kernel(SchedView s) {
+  for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < s.RM; id += gridDim.x * blockDim.x) {
+    const int r = s.rep[id];
+    if (r >= 0 && r != id) s.enc.node2row[id] = s.enc.node2row[r];
+  }
+}
+
+// predecessor rows of every value row (descending node index, as dir[0]) and the (predecessor row, row) pairs
+__global__ void merge_fill_kernel(SchedView s) {
+  const int N = s.N;
+  SchedDir& M = s.enc;
+  for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < s.RM; id += gridDim.x * blockDim.x) {
+    if (s.rep[id] != id) continue;
+    const int b = id / N, row = M.node2row[id];
+    int p = M.csr_ptr[row];
+    const uint32_t* pm = s.rowbits + (size_t)id * DVAE_BITW;
+    for (int w = DVAE_BITW - 1; w >= 0; --w) {
+      uint32_t m = pm[w];
+      while (m) {
+        const int bit = 31 - __clz(m);
+        m &= ~(1u << bit);
+        const int u = M.node2row[b * N + w * 32 + bit];
+        M.csr_idx[p] = u;
+        s.pkey[0][p] = u;
+        s.sval[0][p] = row;
+        ++p;
+      }
+    }
+  }
+}
+
+// csc_ptr[u] = first sorted pair whose predecessor row is >= u
+__global__ void merge_csc_ptr_kernel(SchedView s) {
+  const int* key = s.pkey[1];
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u <= s.RM; u += gridDim.x * blockDim.x) {
+    int lo = 0, hi = s.EM;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (key[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    s.enc.csc_ptr[u] = lo;
+  }
+}
+
+__global__ void merge_info_kernel(SchedView s, int ran) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int N = s.N, B = s.B;
+  int* mi = s.info + DVAE_SCHED_MERGE_AT(N);
+  if (!ran) { mi[0] = 0; return; }
+  mi[0] = (s.err[1] == 0 && s.err[4] == 0) ? 1 : 0;
+  mi[1] = s.enc.pos[(size_t)N * B];
+  mi[2] = s.enc.csr_ptr[s.RM];
+  mi[3] = 0;
+  for (int L = 0; L < N; ++L) mi[4 + L] = s.enc.pos[(size_t)L * B];
+  mi[4 + N] = mi[1];
+  for (int L = 0; L <= N; ++L) mi[5 + N + L] = s.enc.csc_ptr[mi[4 + L]];   // successor links before each level
+}
+
+int g_merge_min_slots = getenv("DVAE_NO_MERGE") ? -1 : getenv("DVAE_MERGE_MIN") ? atoi(getenv("DVAE_MERGE_MIN")) : 16384;
+
+// *ran = 1 when the value rows were built (0: the sorts' scratch would not fit -- rows stay unshared)
+int merge_rows(SchedView& s, hipStream_t st, int* ran) {
+  *ran = 0;
+  const int B = s.B, N = s.N;
+  const int grid_r = std::min(cdiv(s.RM, 256), 2048);
+  // the sorts' scratch must fit what the schedule reserved for them
+  size_t need1 = 0, need2 = 0;
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, need1, s.skey[0], s.skey[1], s.sval[0], s.sval[1], s.RM, 0, 64, st) != hipSuccess ||
+      hipcub::DeviceRadixSort::SortPairs(nullptr, need2, s.pkey[0], s.pkey[1], s.sval[0], s.enc.csc_idx, s.EM, 0, 31, st) != hipSuccess ||
+      std::max(need1, need2) > s.sort_tmp_bytes)
+    return DVAE_OK;
+  DVAE_CHECK_HIP(hipMemsetAsync(s.err + 4, 0, sizeof(int), st));
+  hipLaunchKernelGGL(merge_hash_kernel, dim3(B), dim3(64), 0, st, s);
+  DVAE_LAUNCH_CHECK();
+  size_t tb = s.sort_tmp_bytes;
+  DVAE_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, tb, s.skey[0], s.skey[1], s.sval[0], s.sval[1], s.RM, 0, 64, st));
+  hipLaunchKernelGGL(merge_flags_kernel, dim3(grid_r), dim3(256), 0, st, s);
+  DVAE_LAUNCH_CHECK();
+  DVAE_TRY(exclusive_scan(s.gidx, s.gidx, s.RM, s.scan_tmp, st));
+  hipLaunchKernelGGL(merge_first_kernel, dim3(grid_r), dim3(256), 0, st, s);
+  hipLaunchKernelGGL(merge_rep_kernel, dim3(grid_r), dim3(256), 0, st, s);
+  hipLaunchKernelGGL(merge_check_kernel, dim3(grid_r), dim3(256), 0, st, s);
+  hipLaunchKernelGGL(merge_count_kernel, dim3(B), dim3(64), 0, st, s);
+  DVAE_LAUNCH_CHECK();
+  DVAE_TRY(exclusive_scan(s.enc.pos, s.enc.pos, N * B, s.scan_tmp, st));
+  DVAE_CHECK_HIP(hipMemsetAsync(s.enc.csr_ptr, 0, sizeof(int) * (s.RM + 1), st));
+  DVAE_CHECK_HIP(hipMemsetAsync(s.enc.row_graph, 0, sizeof(int) * s.RM, st));   // rows beyond the last value row name node (0,0)
+  DVAE_CHECK_HIP(hipMemsetAsync(s.enc.row_node, 0, sizeof(int) * s.RM, st));
+  hipLaunchKernelGGL(merge_assign_kernel, dim3(B), dim3(64), 0, st, s);
+  hipLaunchKernelGGL(merge_map_kernel, dim3(grid_r), dim3(256), 0, st, s);
+  DVAE_LAUNCH_CHECK();
+  DVAE_TRY(exclusive_scan(s.enc.csr_ptr, s.enc.csr_ptr, s.RM, s.scan_tmp, st));
+  DVAE_CHECK_HIP(hipMemsetAsync(s.pkey[0], 0x7f, sizeof(int) * (size_t)s.EM, st));   // unused slots sort last
+  hipLaunchKernelGGL(merge_fill_kernel, dim3(grid_r), dim3(256), 0, st, s);
+  DVAE_LAUNCH_CHECK();
+  tb = s.sort_tmp_bytes;
+  DVAE_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(s.sort_tmp, tb, s.pkey[0], s.pkey[1], s.sval[0], s.enc.csc_idx, s.EM, 0, 31, st));
+  hipLaunchKernelGGL(merge_csc_ptr_kernel, dim3(std::min(cdiv(s.RM + 1, 256), 2048)), dim3(256), 0, st, s);
+  DVAE_LAUNCH_CHECK();
+  *ran = 1;
+  return DVAE_OK;
+}
+
 }  // namespace
 
 SchedView sched_view(void* base, int B, int N) { return carve(base, B, N, nullptr); }
@@ -402,6 +703,18 @@ extern "C" int dvae_sched_types(const float* x, int B, int N, int C, void* sched
   hipLaunchKernelGGL(sched_types_info_kernel, dim3(1), dim3(64), 0, st, s);
   DVAE_LAUNCH_CHECK();
   DVAE_CHECK_HIP(hipMemcpyAsync(info_host + 5, s.info + 5, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  // shared encoder rows: worth their build from a few thousand nodes up (dvae_enc_merge_tune)
+  int ran = 0;
+  if (g_merge_min_slots >= 0 && s.RM >= g_merge_min_slots) DVAE_TRY(merge_rows(s, st, &ran));
+  hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(64), 0, st, s, ran);
+  DVAE_LAUNCH_CHECK();
+  DVAE_CHECK_HIP(hipMemcpyAsync(info_host + DVAE_SCHED_MERGE_AT(N), s.info + DVAE_SCHED_MERGE_AT(N), (2 * N + 6) * sizeof(int),
+                                hipMemcpyDeviceToHost, st));
+  return DVAE_OK;
+}
+
+extern "C" int dvae_enc_merge_tune(int min_node_slots) {
+  g_merge_min_slots = min_node_slots;
   return DVAE_OK;
 }
 
@@ -474,6 +787,14 @@ extern "C" int dvae_sched_export(const void* sched, int B, int N, int which, int
     case 7: src = s.dir[0].row_node; n = s.RM; break;
     case 8: src = s.a_rows; n = s.EM; break;
     case 9: src = s.a_skip; n = s.EM; break;
+    case 10: src = s.enc.node2row; n = s.RM; break;
+    case 11: src = s.enc.row_graph; n = s.RM; break;
+    case 12: src = s.enc.row_node; n = s.RM; break;
+    case 13: src = s.enc.csr_ptr; n = (size_t)s.RM + 1; break;
+    case 14: src = s.enc.csr_idx; n = s.EM; break;
+    case 15: src = s.enc.csc_ptr; n = (size_t)s.RM + 1; break;
+    case 16: src = s.enc.csc_idx; n = s.EM; break;
+    case 17: src = s.rep; n = s.RM; break;
     default: dvae_set_error("sched_export: unknown array %d", which); return DVAE_ERR_ARG;
   }
   if (n > max_ints) n = max_ints;

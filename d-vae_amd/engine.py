@@ -182,6 +182,12 @@ class Schedule:
         return int(self.info[5]) == 1
 
     @property
+    def shared_rows(self):
+        """(value rows, links between them) of the encoder's forward sweep when dvae_sched_types shared them, else None."""
+        m = _lib.sched_merge_at(self.N)
+        return (int(self.info[m + 1]), int(self.info[m + 2])) if int(self.info[m]) == 1 else None
+
+    @property
     def info_ptr(self):
         return ctypes.c_void_p(self.info.ctypes.data)
 

@@ -83,7 +83,7 @@ class Encoder(nn.Module):
         g, x, sizes = _batch_parts(X)
         self._check(g, x)
         if sched is None:
-            sched = E.Schedule(g, sizes, want_reverse=self.is_bidirectional)
+            sched = E.Schedule(g, sizes, want_reverse=self.is_bidirectional, x=x)
         return E.EncoderFn.apply(self, sched, E._f32c(x), *self.hip_params())
 
     def predict(self, X):
@@ -92,7 +92,7 @@ class Encoder(nn.Module):
     def node_states(self, X):
         """Per-node hidden states [B,N,H] (forward, reverse or None) -- parity tests."""
         g, x, sizes = _batch_parts(X)
-        sched = E.Schedule(g, sizes, want_reverse=self.is_bidirectional)
+        sched = E.Schedule(g, sizes, want_reverse=self.is_bidirectional, x=x)
         dims = E._dims_for(self._dims, sched.B, sched.N)
         with torch.no_grad():
             P = self._pack.pack(dims, self.hip_params())

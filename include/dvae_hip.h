@@ -138,8 +138,11 @@ int dvae_hbm_profile_read(double* out12_host);
  *              prefix rows that add_edge reads (dvae_model.py:210-220 scores pair (i,j) on the
  *              prefix holding the predecessors above j, so a node's full prefix is read only
  *              when node 0 is not among its predecessors)
+ *          [8+4N+4 ..] shared encoder rows (dvae_sched_types): [+0] 1 when valid, [+1] value rows, [+2] links
+ *              between them, [+3] spare, [+4 .. +4+N] level starts in value rows, [+5+N .. +5+2N] successor
+ *              links before each level start
  * ---------------------------------------------------------------------- */
-#define DVAE_SCHED_INFO_INTS(N) (8 + 4 * ((N) + 1))
+#define DVAE_SCHED_INFO_INTS(N) (8 + 6 * ((N) + 1) + 4)
 size_t dvae_sched_bytes(int B, int N);
 int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_reverse, void* sched,
                      int* info_host, void* stream);
@@ -150,14 +153,25 @@ int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_re
  * computing them per row (about a third of add_edge's first-layer work at ENAS sizes);
  * without this call, or with other encodings, every row is computed.  It also sets
  * info_host[6] (see above): the last node of a graph is never a candidate predecessor, so its
- * W1b product is skipped when those nodes form the (contiguous) last level. */
+ * W1b product is skipped when those nodes form the (contiguous) last level.
+ * Shared encoder rows: with one-hot encodings and at least dvae_enc_merge_tune's row count (default 16384
+ * node slots B*N), the call also numbers the VALUES of the forward encoder sweep -- nodes with the same index,
+ * type and predecessor values have the same state (dvae_model.py:63-87 reads nothing else) -- and builds the
+ * sweep's schedule over one row per value; dvae_encoder_fwd / _bwd then run the forward-direction sweep on those
+ * rows (every graph's outputs are unchanged: the shared row is the row each of its nodes would have computed).
+ * The grouping is by a 128-bit hash and then CHECKED field by field; a mismatch turns sharing off for the batch. */
 int dvae_sched_types(const float* x, int B, int N, int C, void* sched, int* info_host, void* stream);
 /* copies one int32 array of the schedule to `out` (device); which:
  * 0 level_fwd[B*N] 1 level_rev[B*N] 2 node2row_fwd[B*N] 3 node2row_rev[B*N]
  * 4 csr_ptr_fwd[R+1] 5 csr_idx_fwd[E] 6 row_graph_fwd[R] 7 row_node_fwd[R]
- * 8 scored edge prefix rows (R + edge index, ascending) 9 the unscored ones */
+ * 8 scored edge prefix rows (R + edge index, ascending) 9 the unscored ones
+ * shared encoder rows: 10 node2row[B*N] 11 row_graph 12 row_node 13 csr_ptr[B*N+1] 14 csr_idx 15 csc_ptr[B*N+1]
+ * 16 csc_idx 17 representative node id of every node [B*N] */
 int dvae_sched_export(const void* sched, int B, int N, int which, int* out, size_t max_ints,
                       void* stream);
+/* tuning / test knob: dvae_sched_types shares encoder rows from this many node slots (B*N) up; 0 = always,
+ * negative = never.  No counterpart in the reference (it walks every node of every graph). */
+int dvae_enc_merge_tune(int min_node_slots);
 
 /* ------------------------------------------------------------------------
  * Parameter packing.  Weights keep the reference's state_dict names and
