@@ -506,6 +506,14 @@ def main():
             res["config"]["report"] = {k: (round(float(v), 6) if isinstance(v, (int, float)) else v) for k, v in report.items()}
         if cfg["kind"] == "train":
             res["config"]["final_loss"] = final
+            last = getattr(model, "_step_keep", None)
+            if last is not None:
+                # the encoder's forward sweep runs on one row per distinct node VALUE (index, type, predecessor values) of the
+                # batch -- exact common-subexpression sharing, every graph's outputs unchanged; the algorithmic
+                # FLOP count above still charges one row per node, as the reference computes
+                sr = last[0].shared_rows
+                res["config"]["encoder_rows"] = {"nodes": last[0].R, "value_rows": sr[0] if sr else last[0].R,
+                                                 "shared": sr is not None}
             if cfg["N"] <= 16:
                 g0 = batches[0]['graph'][:256].cpu()
                 res["config"]["depth"] = round(dvae_amd.synth.graph_stats(g0)[1], 2)

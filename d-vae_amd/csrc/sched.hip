@@ -643,7 +643,7 @@ __global__ void merge_info_kernel(SchedView s, int ran) {
   for (int L = 0; L <= N; ++L) mi[5 + N + L] = s.enc.csc_ptr[mi[4 + L]];   // successor links before each level
 }
 
-int g_merge_min_slots = getenv("DVAE_NO_MERGE") ? -1 : getenv("DVAE_MERGE_MIN") ? atoi(getenv("DVAE_MERGE_MIN")) : 16384;
+int g_merge_min_slots = getenv("DVAE_NO_MERGE") ? -1 : getenv("DVAE_MERGE_MIN") ? atoi(getenv("DVAE_MERGE_MIN")) : 8192;
 
 // *ran = 1 when the value rows were built (0: the sorts' scratch would not fit -- rows stay unshared)
 int merge_rows(SchedView& s, hipStream_t st, int* ran) {

@@ -154,7 +154,7 @@ int dvae_sched_build(const float* g, const int* sizes, int B, int N, int want_re
  * without this call, or with other encodings, every row is computed.  It also sets
  * info_host[6] (see above): the last node of a graph is never a candidate predecessor, so its
  * W1b product is skipped when those nodes form the (contiguous) last level.
- * Shared encoder rows: with one-hot encodings and at least dvae_enc_merge_tune's row count (default 16384
+ * Shared encoder rows: with one-hot encodings and at least dvae_enc_merge_tune's row count (default 8192
  * node slots B*N), the call also numbers the VALUES of the forward encoder sweep -- nodes with the same index,
  * type and predecessor values have the same state (dvae_model.py:63-87 reads nothing else) -- and builds the
  * sweep's schedule over one row per value; dvae_encoder_fwd / _bwd then run the forward-direction sweep on those

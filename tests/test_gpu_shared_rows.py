@@ -18,12 +18,12 @@ def _default_slots():
     import os
     if os.environ.get("DVAE_NO_MERGE"):
         return -1
-    return int(os.environ.get("DVAE_MERGE_MIN", 16384))
+    return int(os.environ.get("DVAE_MERGE_MIN", 8192))
 
 
 @pytest.fixture
 def share_always():
-    """Share rows at any batch size (the default starts at 16384 node slots)."""
+    """Share rows at any batch size (the default starts at 8192 node slots)."""
     from dvae_amd import _lib
     lib = _lib.load()
     lib.dvae_enc_merge_tune(0)
@@ -105,9 +105,9 @@ def test_not_shared_without_types_or_below_threshold(cuda):
     xs = x.clone()
     xs[3, 2] *= 0.5                                                        # not one-hot
     try:
-        lib.dvae_enc_merge_tune(16384)                                     # the default
+        lib.dvae_enc_merge_tune(8192)                                     # the default
         assert E.Schedule(g.to(cuda)).shared_rows is None                  # no dvae_sched_types call
-        assert E.Schedule(g.to(cuda), x=x.to(cuda)).shared_rows is None    # 128 node slots < 16384
+        assert E.Schedule(g.to(cuda), x=x.to(cuda)).shared_rows is None    # 128 node slots < 8192
         lib.dvae_enc_merge_tune(0)
         assert E.Schedule(g.to(cuda), x=xs.to(cuda)).shared_rows is None
         assert E.Schedule(g.to(cuda), x=x.to(cuda)).shared_rows is not None

@@ -174,3 +174,30 @@ def test_bn_dataset_parser_and_split(tmp_path):
     ds = data.NASDataset(str(f), split='val', fmt='str', task_type='bn')
     for i in range(len(ds)):
         assert np.array_equal(ds[i]['graph'].numpy(), r['val_str'][i])
+
+
+def test_nodes_with_one_value_have_one_encoder_state():
+    """The premise of the library's shared encoder rows, on the restated reference itself: nodes that
+    oracle/levels.py shared_encoder_rows gives one value hold bit-identical encoder states in the dense walk
+    (dvae_model.py:63-87 computes a state from the node's index, type and predecessor states only)."""
+    import numpy as np
+    from oracle import dense_ref as O
+    from oracle import levels as L
+    import dvae_amd
+    from argparse import Namespace
+    from helpers import fill_weights, oracle_sd
+    B, N, C = 40, 7, 3
+    g, x = dvae_amd.synth.random_dags(B, N, C, 0.4, 17, chain=True)
+    for mod in (None, "bn"):
+        model = fill_weights(dvae_amd.Dvae(Namespace(dataset_file=None, mod=mod, bidirectional=False, num_classes=C,
+                                                     max_seq=N, hidden_state_size=32)), seed=2)
+        with torch.no_grad():
+            states = O.encoder_forward(oracle_sd(model), g, x, mod, False, return_states=True)[3]
+        rep, node2row, _, _ = L.shared_encoder_rows(g.numpy(), x.argmax(2).numpy())
+        flat = states.reshape(B * N, -1)
+        shared = 0
+        for i, r in enumerate(rep):
+            if r != i:
+                shared += 1
+                assert torch.equal(flat[i], flat[int(r)])
+        assert shared > B          # most nodes of the first levels repeat
