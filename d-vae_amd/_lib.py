@@ -85,7 +85,8 @@ SIGNATURES = {
     "dvae_small_rows_tune": (c_int, [c_int]),
     "dvae_enc_merge_tune": (c_int, [c_int]),
     "dvae_pair_path": (c_int, [c_int, c_int]),
-    "dvae_typed_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dvae_typed_colsum": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                          c_void_p]),
     "dvae_wgrad_split_tune": (c_int, [ctypes.c_double, c_int]),
     "dvae_gemm_profile": (c_int, [c_int]),
     "dvae_gemm_profile_read": (c_int, [c_void_p]),

@@ -66,6 +66,7 @@ void carve_sweep(Carver& c, SweepBufs& s, int prefix, int R, int E, int HP, int 
   s.GM = c.f(r * HP);
   s.XP = c.f(rh * 32);
   s.PX = c.f(r * PP);
+  s.XT = reinterpret_cast<int*>(c.f(rh));
   if (prefix) {
     s.HV = c.f(rh * HP);
     s.Hn = c.f(r * HP);
@@ -202,6 +203,7 @@ thread_local Events g_events;
 // ---- GEMM shorthands ---------------------------------------------------------
 struct G {
   float* ws; hipStream_t st; int prio = 0; int bulk = 0;
+  float* part = nullptr; size_t part_floats = 0;   // the stream's scratch for column sums (Scratch::part), when the caller has one
   // Y[M][N] (+)= X[M][K] W[N][K]^T + bias
   int nt(const float* X, int ldx, const float* W, int ldw, float* Y, int ldy, int M, int N, int K,
          const float* bias = nullptr, int relu = 0, int acc = 0, const int* rows = nullptr,
@@ -538,8 +540,11 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
 // (k_type_gru_bwd) instead of per-row GH/GHN entries
 struct TypeGrad { const float *TG, *TGN, *XPT; };
 struct WgradOut { float *Ggru, *Ggm, *Xgru, *Xgm; };
+// onehot: every node encoding of the batch is one-hot (info[5]): the products against the one-hot tables XP / PX are
+// column sums per type / per position (k_typed_colsum: one streaming pass at 3.5-5 TB/s instead of a [3HP x 32] tile grid
+// that walks the table at 1.3) and the tables themselves are never built
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                const WgradOut& o, bool seeded, const G& g, const TypeGrad* tg, int La, int Lb, bool first) {
+                const WgradOut& o, bool seeded, const G& g, const TypeGrad* tg, int La, int Lb, bool first, bool onehot) {
   const int HP = d.HP, PP = pos_cols(d), R = lv.R;
   hipStream_t st = g.st;
   const int RH = R > 0 ? b.RH : 0;
@@ -548,14 +553,23 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
   const int acc = first ? 0 : 1;
   const bool low = La == 0;
   if (R <= 0) { La = 0; Lb = 0; }
+  static const bool typed_off = getenv("DVAE_NO_TYPED_WGRAD") != nullptr;   // A-B tests: the TN products
+  const bool typed = onehot && !typed_off && g.part != nullptr;
+  const bool typed_pos = typed && d.mod == 0 && d.npos < 32 && d.npos < PP;   // position one-hot: at most 31 positions
   if (first) {
-    DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
-    if (d.mod == 0) DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
-    else DVAE_TRY(k_build_xp(S, 0, R, x, d.N, d.C, b.PX, st));
+    if (typed) DVAE_TRY(k_build_xt(S, b.prefix, RH, x, d.N, d.C, b.XT, st));
+    else DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
+    if (d.mod == 0 && !typed_pos) DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
+    else if (d.mod != 0 && !typed) DVAE_TRY(k_build_xp(S, 0, R, x, d.N, d.C, b.PX, st));
   }
   float* Xn = o.Xgru + (size_t)3 * HP * 32;
   auto gru_rows = [&](int r0, int r1, int a) -> int {   // dW_ih, db_ih, db_hh = (dgh | dn_pre)^T . (x | 1)
     if (r1 <= r0 && a) return DVAE_OK;
+    if (typed) {
+      DVAE_TRY(k_typed_colsum(b.GH + (size_t)r0 * 3 * HP, 3 * HP, r1 - r0, 3 * HP, b.XT + r0, d.C, o.Xgru, g.part, g.part_floats,
+                              st, 32, a));
+      return k_typed_colsum(b.GHN + (size_t)r0 * HP, HP, r1 - r0, HP, b.XT + r0, d.C, Xn, g.part, g.part_floats, st, 32, a);
+    }
     DVAE_TRY(g.tn(b.GH + (size_t)r0 * 3 * HP, 3 * HP, b.XP + (size_t)r0 * 32, 32, o.Xgru, 32, 3 * HP, 32, r1 - r0, a));
     return g.tn(b.GHN + (size_t)r0 * HP, HP, b.XP + (size_t)r0 * 32, 32, Xn, 32, HP, 32, r1 - r0, a);
   };
@@ -589,7 +603,13 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
   if (d.mod == 0) {
     const int r1 = std::min(n1, Rg);
     DVAE_TRY(g.tn(b.GMP + (size_t)n0 * 2 * HP, 2 * HP, b.Hn + (size_t)n0 * HP, HP, o.Ggm, HP, 2 * HP, HP, r1 - n0, acc));
-    DVAE_TRY(g.tn(b.GMP + (size_t)n0 * 2 * HP, 2 * HP, b.PX + (size_t)n0 * PP, PP, o.Xgm, PP, 2 * HP, PP, r1 - n0, acc));
+    if (typed_pos)   // the rows' positions are the schedule's row_node
+      DVAE_TRY(k_typed_colsum(b.GMP + (size_t)n0 * 2 * HP, 2 * HP, r1 - n0, 2 * HP, S.row_node + n0, d.npos, o.Xgm, g.part,
+                              g.part_floats, st, PP, acc));
+    else
+      DVAE_TRY(g.tn(b.GMP + (size_t)n0 * 2 * HP, 2 * HP, b.PX + (size_t)n0 * PP, PP, o.Xgm, PP, 2 * HP, PP, r1 - n0, acc));
+  } else if (typed) {
+    DVAE_TRY(k_typed_colsum(b.GMP, 2 * HP, R, 2 * HP, b.XT, d.C, o.Xgm, g.part, g.part_floats, st, 32, acc));
   } else {
     DVAE_TRY(g.tn(b.GMP, 2 * HP, b.PX, 32, o.Xgm, 32, 2 * HP, 32, R, acc));
   }
@@ -622,7 +642,7 @@ int wgrad_split_level(const dvae_dims& d, const Levels& lv, bool prefix, bool tw
 
 // backward sweep on the chain + its weight-gradient products on the side stream
 int sweep_bwd_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
-                    const float* x, const WgradOut& o, bool seeded, const G& g, const G& gs, Events& ev,
+                    const float* x, const WgradOut& o, bool seeded, const G& g, const G& gs, Events& ev, bool onehot,
                     bool k0_shared = false, const TypeGrad* tg = nullptr) {
   const int L0 = wgrad_split_level(d, lv, b.prefix, g.st != gs.st);
   bool early = false;
@@ -630,11 +650,11 @@ int sweep_bwd_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, Swe
     if (L != L0 || L0 <= 0) return DVAE_OK;
     DVAE_TRY(ev.edge(g.st, gs.st));
     early = true;
-    return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, L0, lv.nlev, true);
+    return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, L0, lv.nlev, true, onehot);
   };
   DVAE_TRY(sweep_bwd(d, S, lv, b, w, seeded, g, k0_shared, after));
   DVAE_TRY(ev.edge(g.st, gs.st));
-  return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, 0, early ? L0 : lv.nlev, !early);
+  return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, 0, early ? L0 : lv.nlev, !early, onehot);
 }
 
 }  // namespace
@@ -713,7 +733,7 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
   EncWs w = enc_ws(d, lf.R, lf.E, ws);
   const EncLayout L = enc_layout(d);
   const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
-  const G gs{w.sc[1].gemm_ws, sd, 0, sd != st ? 1 : 0};       // weight-gradient products
+  const G gs{w.sc[1].gemm_ws, sd, 0, sd != st ? 1 : 0, w.sc[1].part, w.sc[1].part_floats};       // weight-gradient products
   const Scratch& ssc = w.sc[1];
   Events& ev = g_events;
   const int HP = d.HP, B = d.B, ZP = d.ZP;
@@ -757,12 +777,12 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
     DVAE_TRY(gs.tn(w.DQ, HP, w.r.Hn, HP, Gp + L.W01 + HP, 2 * HP, HP, HP, lr.R));
     DVAE_TRY(k_colsum(w.DQ, HP, lr.R, HP, Gp + L.b01, ssc.part, ssc.part_floats, sd));
     DVAE_TRY(sweep_bwd_wgrad(d, sv.dir[1], lr, w.r, wr, x,
-                             WgradOut{Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b}, false, g, gs, ev));
+                             WgradOut{Gp + L.gru_b, Gp + L.gm_b, Gp + L.xg_gru_b, Gp + L.xg_gm_b}, false, g, gs, ev, info[5] == 1));
   } else {
     DVAE_TRY(k_take_last_bwd(Sf, sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
   DVAE_TRY(sweep_bwd_wgrad(d, Sf, lfs, w.f, wf, x,
-                           WgradOut{Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f}, false, g, gs, ev));
+                           WgradOut{Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f}, false, g, gs, ev, info[5] == 1));
   return DVAE_OK;
 }
 
@@ -877,7 +897,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DecWs w = dec_ws(d, lv.R, lv.E, ws);
   const DecLayout L = dec_layout(d);
   const G g{w.sc[0].gemm_ws, st, sd != st ? 1 : 0};
-  const G gs{w.sc[1].gemm_ws, sd, 0, sd != st ? 1 : 0};       // weight-gradient products
+  const G gs{w.sc[1].gemm_ws, sd, 0, sd != st ? 1 : 0, w.sc[1].part, w.sc[1].part_floats};       // weight-gradient products
   const Scratch& msc = w.sc[0];
   const Scratch& ssc = w.sc[1];
   Events& ev = g_events;
@@ -1007,7 +1027,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   if (defer_side) DVAE_TRY(side_products());
   const TypeGrad tgrad{w.TG, w.TGN, w.XPT};
   DVAE_TRY(sweep_bwd_wgrad(d, S, lv, w.s, sw, x, WgradOut{Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm}, true,
-                           g, gs, ev, typed, typed ? &tgrad : nullptr));
+                           g, gs, ev, info[5] == 1, typed, typed ? &tgrad : nullptr));
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
 

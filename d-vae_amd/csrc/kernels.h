@@ -37,6 +37,8 @@ struct SweepBufs {
   float* DHn;       // [R][HP]   prefix only: extra gradient of the final states
   float* XP;        // [RH][32]  node encoding | 1 of every row (weight-gradient GEMMs)
   float* PX;        // [R][PP]   None: position one-hot | 1; bn: node encoding | 1 per node
+  int* XT;          // [RH]      node type of every row when every encoding is one-hot (XP / PX as index lists: the skinny
+                    //           weight gradients are then column sums per type, kernels.hip typed_colsum_kernel)
   // prefix sweeps, mod None ("hidden product per node"): the GRU's hidden product of a prefix row is
   // linear in its h_in = sum of the predecessors' gated states, so it is summed from ONE product per
   // node, PG[u] = Whh.GM[u], instead of being computed per prefix row (E + N rows -> N rows)
@@ -98,16 +100,18 @@ int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hip
               const GemmPartials* parts = nullptr, int parts_row0 = 0);
 // one-hot side tables for the skinny weight gradients (see layout.h)
 int k_build_xp(const SchedDir& S, int prefix, int rows, const float* x, int N, int C, float* XP, hipStream_t st);
+// XT[p] = the column of the 1 in the (one-hot) encoding of row p's node
+int k_build_xt(const SchedDir& S, int prefix, int rows, const float* x, int N, int C, int* XT, hipStream_t st);
 int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_t st);
 // out[w] = sum_rows X[row][w]   (W % 4 == 0)
 int k_colsum(const float* X, int ld, int rows, int W, float* out, float* part, size_t part_floats,
              hipStream_t st);
 int k_relu_bwd_colsum(float* D, const float* Y, int ld, int rows, int W, float* out, float* part,
-                      size_t part_floats, hipStream_t st);
-// out[W][32] = X[rows][W]^T . [onehot(row_type[row]) | 1 | 0 ..]: column sums per node type (C < 32 types, every row typed),
-// one streaming pass; the layout of the [W x 32] TN product it replaces
+                      size_t part_floats, hipStream_t st);   // D *= (Y > 0), out = column sums of D
+// out[W][ldo] (+)= X[rows][W]^T . [onehot(row_type[row]) | 1 | 0 ..]: column sums per node type (C < 32 types, every row
+// typed), one streaming pass; the layout of the skinny TN product it replaces
 int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, float* part,
-                   size_t part_floats, hipStream_t st);   // D *= (Y > 0), out = column sums of D
+                   size_t part_floats, hipStream_t st, int ldo = 32, int accumulate = 0);
 
 // [B][N][W] API tensors <-> node-row tables
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st);

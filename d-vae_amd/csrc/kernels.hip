@@ -578,6 +578,18 @@ __global__ void build_xp_kernel(SchedDir S, int prefix, int rows, const float* _
   }
 }
 
+__global__ void build_xt_kernel(SchedDir S, int prefix, int rows, const float* __restrict__ x, int N, int C,
+                                int* __restrict__ XT) {
+  ITEM_LOOP(rows) {
+    const int r = prefix ? S.prow_node[it] : (int)it;
+    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
+    int t = 0;
+    for (int c = 0; c < C; ++c)
+      if (xr[c] != 0.f) t = c;
+    XT[it] = t;
+  }
+}
+
 __global__ void build_px_kernel(SchedDir S, int R, int npos, int PP, float* __restrict__ PX) {
   const long long total = (long long)R * PP;
   ITEM_LOOP(total) {
@@ -621,62 +633,101 @@ __global__ __launch_bounds__(256) void colsum_kernel(float* __restrict__ X, cons
 }
 
 // Column sums per node TYPE: part[chunk][t][w] = sum over the chunk's rows r with row_type[r] == t of X[r][w].
-// This is the skinny product X^T . onehot(type) (the decoder's per-type gradient sums DTT = DA^T . XP, sched.h TypeShare)
-// done as what it is -- one streaming pass over X -- instead of a [W x 32] GEMM tile grid that walks X in 16 KB steps:
-// a block owns 64 columns x one row chunk (16 row lanes x 16 float4 columns, as colsum_kernel); every thread keeps one
-// float4 accumulator per type in LDS, in a slot of its own (no lane ever touches another lane's slot), the row lanes are
-// folded in a fixed order at the end.  Rows whose type is -1 (not one-hot) must not occur (the caller checks info[5]).
-__global__ __launch_bounds__(256) void typed_colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc, int W,
-                                                           const int* __restrict__ row_type, int C, float* __restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) float4 tacc[];   // [C][256]
-  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
-  const int col = blockIdx.x * 64 + cx * 4;
-  const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
-  for (int t = 0; t < C; ++t) tacc[t * 256 + threadIdx.x] = zero4();
-  if (col < W) {
-    int r = r0 + ry;
-    // two rows in flight per lane
-    for (; r + 16 < r1; r += 32) {
-      const int t0 = row_type[r], t1 = row_type[r + 16];
-      const float4 v0 = ld4(X + (size_t)r * ld + col), v1 = ld4(X + (size_t)(r + 16) * ld + col);
-      float4* a0 = tacc + t0 * 256 + threadIdx.x;
-      *a0 = add4(*a0, v0);
-      float4* a1 = tacc + t1 * 256 + threadIdx.x;
-      *a1 = add4(*a1, v1);
-    }
-    if (r < r1) {
-      float4* a0 = tacc + row_type[r] * 256 + threadIdx.x;
-      *a0 = add4(*a0, ld4(X + (size_t)r * ld + col));
-    }
-  }
-  __syncthreads();
-  // lane (ry, cx) folds the 16 row lanes of types ry, ry + 16 for its columns
-  if (col < W)
-    for (int t = ry; t < C; t += 16) {
-      float4 s = tacc[t * 256 + cx];
+// This is the skinny product X^T . onehot(type) (the decoder's per-type gradient sums DTT = DA^T . XP, sched.h TypeShare;
+// the input-weight and bias gradients of the GRU cells; the position columns of the gate/map gradients) done as what it
+// is -- one streaming pass over X -- instead of a [W x 32] GEMM tile grid that walks X in 16 KB steps.  A WAVE takes whole
+// rows, 1 KB (256 columns) at a time, four rows in flight; the row's type is uniform over the wave, so the accumulator of
+// each type is a REGISTER float4 picked by a scalar branch -- no LDS, no atomics.  A block = four waves on rows r, r+1,
+// r+2, r+3 (mod 4) of one row chunk x one group of 256 columns; the waves' sums meet in LDS in wave order.  Rows whose type
+// is outside [0, C) must not occur (the callers check info[5]).  CT = register accumulators (8 / 16 / 32 >= C).
+template <int CT>
+__device__ __forceinline__ void typed_add(float4 (&acc)[CT], int t, const float4& v) {
 #pragma unroll
-      for (int k = 1; k < 16; ++k) s = add4(s, tacc[t * 256 + k * 16 + cx]);
-      st4(part + ((size_t)blockIdx.y * C + t) * W + col, s);
-    }
+  for (int k = 0; k < CT; ++k)
+    if (t == k) acc[k] = add4(acc[k], v);
 }
 
-// out[w][c] = sum over chunks of part[chunk][c][w] (c < C), out[w][C] = the sum over all types (every row has exactly
-// one type: the column of ones of XP), the other columns of the 32 are zero.  A block finishes 8 columns w x 32 entries:
-// thread (wl, c) sums its chunks in order, the totals meet in LDS, and the block writes 1 KB of `out` contiguously.
-__global__ __launch_bounds__(256) void typed_colsum_final_kernel(const float* __restrict__ part, int nch, int C, int W,
-                                                                 float* __restrict__ out) {
-  __shared__ float sh[8][33];
-  const int c = threadIdx.x & 31, wl = threadIdx.x >> 5;
-  const int w = blockIdx.x * 8 + wl;
-  float s = 0.f;
-  if (c < C && w < W)
-    for (int k = 0; k < nch; ++k) s += part[((size_t)k * C + c) * W + w];
-  sh[wl][c] = s;
-  __syncthreads();
-  if (c == C) {
-    for (int t = 0; t < C; ++t) s += sh[wl][t];
+template <int CT>
+__global__ __launch_bounds__(256) void typed_colsum_kernel(const float* __restrict__ X, int ld, int rows, int rpc, int W,
+                                                           const int* __restrict__ row_type, int C, float* __restrict__ part) {
+  __shared__ float4 sh[3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 256 + lane * 4;
+  const bool on = col < W;
+  const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+  float4 acc[CT];
+#pragma unroll
+  for (int k = 0; k < CT; ++k) acc[k] = zero4();
+  const float* xc = X + (on ? col : 0);
+  int r = r0 + wave;
+  for (; r + 12 < r1; r += 16) {
+    const int t0 = __builtin_amdgcn_readfirstlane(row_type[r]), t1 = __builtin_amdgcn_readfirstlane(row_type[r + 4]);
+    const int t2 = __builtin_amdgcn_readfirstlane(row_type[r + 8]), t3 = __builtin_amdgcn_readfirstlane(row_type[r + 12]);
+    float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4();
+    if (on) {
+      v0 = ld4(xc + (size_t)r * ld);
+      v1 = ld4(xc + (size_t)(r + 4) * ld);
+      v2 = ld4(xc + (size_t)(r + 8) * ld);
+      v3 = ld4(xc + (size_t)(r + 12) * ld);
+    }
+    typed_add<CT>(acc, t0, v0);
+    typed_add<CT>(acc, t1, v1);
+    typed_add<CT>(acc, t2, v2);
+    typed_add<CT>(acc, t3, v3);
   }
-  if (w < W) out[(size_t)w * 32 + c] = s;
+  for (; r < r1; r += 4) {
+    const int t0 = __builtin_amdgcn_readfirstlane(row_type[r]);
+    typed_add<CT>(acc, t0, on ? ld4(xc + (size_t)r * ld) : zero4());
+  }
+#pragma unroll
+  for (int t = 0; t < CT; ++t) {
+    if (t < C) {   // uniform
+      if (wave) sh[wave - 1][lane] = acc[t];
+      __syncthreads();
+      if (wave == 0 && on)
+        st4(part + ((size_t)blockIdx.y * C + t) * W + col, add4(add4(acc[t], sh[0][lane]), add4(sh[1][lane], sh[2][lane])));
+      __syncthreads();
+    }
+  }
+}
+
+// out[w][c] (+)= sum over chunks of part[chunk][c][w] for c < C, out[w][C] (+)= the sum over all types (every row has
+// exactly one type: the column of ones of the one-hot table), the other columns of the ldo are zero (set, not added).
+// Block (x, c): 16 float4 of w for output column c, sixteen lanes per sum over the chunks (four loads in flight each),
+// folded in lane order.
+__global__ __launch_bounds__(256) void typed_colsum_final_kernel(const float* __restrict__ part, int nch, int C, int W,
+                                                                 float* __restrict__ out, int ldo, int accumulate) {
+  __shared__ float4 sh[16][16];
+  const int wq = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.y, w = (blockIdx.x * 16 + wq) * 4;
+  const bool on = w < W;
+  float4 s = zero4();
+  if (on && c <= C) {
+    const int t0 = c < C ? c : 0, t1 = c < C ? c + 1 : C;
+    const size_t kstep = (size_t)C * W;
+    for (int t = t0; t < t1; ++t) {
+      const float* q = part + (size_t)t * W + w;
+      int k = kl;
+      for (; k + 48 < nch; k += 64) {
+        const float4 a0 = ld4(q + k * kstep), a1 = ld4(q + (k + 16) * kstep), a2 = ld4(q + (k + 32) * kstep),
+                     a3 = ld4(q + (k + 48) * kstep);
+        s = add4(add4(s, a0), add4(add4(a1, a2), a3));
+      }
+      for (; k < nch; k += 16) s = add4(s, ld4(q + k * kstep));
+    }
+  }
+  sh[kl][wq] = s;
+  __syncthreads();
+  if (kl == 0 && on) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s = add4(s, sh[k][wq]);
+    float* o = out + (size_t)w * ldo + c;
+    if (accumulate && c <= C) {
+      o[0] += s.x; o[ldo] += s.y; o[2 * (size_t)ldo] += s.z; o[3 * (size_t)ldo] += s.w;
+    } else if (!accumulate) {
+      o[0] = s.x; o[ldo] = s.y; o[2 * (size_t)ldo] = s.z; o[3 * (size_t)ldo] = s.w;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1534,6 +1585,13 @@ int k_build_xp(const SchedDir& S, int prefix, int rows, const float* x, int N, i
   return DVAE_OK;
 }
 
+int k_build_xt(const SchedDir& S, int prefix, int rows, const float* x, int N, int C, int* XT, hipStream_t st) {
+  if (rows <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(build_xt_kernel, grid_for(rows), dim3(256), 0, st, S, prefix, rows, x, N, C, XT);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
 int k_build_px(const SchedDir& S, int R, int npos, int PP, float* PX, hipStream_t st) {
   if (R <= 0) return DVAE_OK;
   hipLaunchKernelGGL(build_px_kernel, grid_for((long long)R * PP), dim3(256), 0, st, S, R, npos, PP, PX);
@@ -1570,45 +1628,35 @@ int k_relu_bwd_colsum(float* D, const float* Y, int ld, int rows, int W, float* 
   return colsum_launch(D, Y, ld, rows, W, out, part, part_floats, st);
 }
 
-// out[W][32] = X[rows][W]^T . [onehot(row_type) | 1 | 0..]  (the layout of the TN product it replaces); C < 32 types
+// out[W][ldo] (+)= X[rows][W]^T . [onehot(row_type) | 1 | 0..]  (the layout of the TN product it replaces); C < ldo types
 int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, float* part,
-                   size_t part_floats, hipStream_t st) {
-  DVAE_REQUIRE((W & 3) == 0 && (ld & 3) == 0 && C >= 1 && C < 32, "typed_colsum: widths must be multiples of 4, 1 <= C < 32");
+                   size_t part_floats, hipStream_t st, int ldo, int accumulate) {
+  DVAE_REQUIRE((W & 3) == 0 && (ld & 3) == 0 && C >= 1 && C < 32 && C < ldo, "typed_colsum: widths must be multiples of 4, 1 <= C < 32");
   if (rows <= 0) {
-    DVAE_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)W * 32 * 4, st));
+    if (!accumulate) DVAE_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)W * ldo * 4, st));
     return DVAE_OK;
   }
-  const int gx = cdiv(W, 64);
-  int nch = std::max(1, std::min(cdiv(2048, gx), cdiv(rows, 128)));
-  nch = (int)std::max<size_t>(1, std::min<size_t>(nch, part_floats / ((size_t)W * C)));
   DVAE_REQUIRE(part_floats >= (size_t)W * C, "typed_colsum: scratch too small");
+  const int gx = cdiv(W, 256);
+  int nch = std::max(1, std::min(cdiv(1024, gx), cdiv(rows, 64)));
+  nch = (int)std::max<size_t>(1, std::min<size_t>(nch, part_floats / ((size_t)W * C)));
   const int rpc = std::max(1, cdiv(rows, nch));
   nch = std::max(1, cdiv(rows, rpc));
-  const size_t lds = (size_t)C * 256 * sizeof(float4);
-  if (lds > 64 * 1024) {   // more than 64 KB of LDS is opt-in (17 or more node types)
-    static std::once_flag big_lds[16];
-    int dev = 0;
-    DVAE_CHECK_HIP(hipGetDevice(&dev));
-    hipError_t err = hipSuccess;
-    std::call_once(big_lds[dev & 15], [&] {
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(typed_colsum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                31 * 256 * (int)sizeof(float4));
-    });
-    DVAE_CHECK_HIP(err);
-  }
-  hipLaunchKernelGGL(typed_colsum_kernel, dim3(gx, nch), dim3(256), lds, st, X, ld, rows, rpc, W, row_type, C, part);
+  if (C <= 8) hipLaunchKernelGGL(typed_colsum_kernel<8>, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, row_type, C, part);
+  else if (C <= 16) hipLaunchKernelGGL(typed_colsum_kernel<16>, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, row_type, C, part);
+  else hipLaunchKernelGGL(typed_colsum_kernel<32>, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, row_type, C, part);
   DVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 8)), dim3(256), 0, st, part, nch, C, W, out);
+  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 64), ldo), dim3(256), 0, st, part, nch, C, W, out, ldo, accumulate);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
 
 // unit-test surface of k_typed_colsum (include/dvae_hip.h)
-extern "C" int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out32,
-                                 float* part, size_t part_floats, void* stream) {
-  DVAE_REQUIRE(X && row_type && out32 && part, "typed_colsum: null pointer");
+extern "C" int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, int ldo,
+                                 int accumulate, float* part, size_t part_floats, void* stream) {
+  DVAE_REQUIRE(X && row_type && out && part, "typed_colsum: null pointer");
   DVAE_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)part & 15) == 0, "typed_colsum: operands must be 16-byte aligned");
-  return k_typed_colsum(X, ld, rows, W, row_type, C, out32, part, part_floats, (hipStream_t)stream);
+  return k_typed_colsum(X, ld, rows, W, row_type, C, out, part, part_floats, (hipStream_t)stream, ldo, accumulate);
 }
 
 int k_nodes_to_dense(const SchedDir& S, int B, int N, const float* T, int ld, float* out, int W, hipStream_t st) {

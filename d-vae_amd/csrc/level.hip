@@ -509,8 +509,6 @@ __global__ __launch_bounds__(NW * 64) void small_kernel(LevelCore p, Epi e) {
   constexpr int A_FL = 32 * SLD;
   constexpr int B_FL = BKM ? G * SBK * SKN : G * 32 * SLD;
   constexpr int STAGE = A_FL + B_FL;                 // per wave
-  constexpr int RED = G * 16 * 64;                   // per wave
-  constexpr int LDS_FL = (STAGE > RED ? STAGE : RED) * NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.prio) __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -298,10 +298,13 @@ int dvae_small_rows_tune(int rows);
 /* Per-type column sums (unit-test surface): out32[w][c] = sum over the rows of type c of X[row][w] for c < C, out32[w][C] =
  * the sum over all rows, the other entries of the 32 zero -- the product X^T . [onehot(type) | 1] of the decoder's per-type
  * gradient sums (the backward of Decoder.forward's k = 0 states, dvae_model.py:203-207, shared by node type) as one
- * streaming pass.  row_type[rows] in [0, C), C < 32; W, ld multiples of 4; part: scratch of at least W * C floats (more
- * scratch = more row chunks in flight). */
-int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out32,
-                      float* part, size_t part_floats, void* stream);
+ * streaming pass.  The same kernel forms the GRU cells' input-weight / bias gradients (X = dgh, types = node types,
+ * dvae_model.py:83,244) and the position columns of the gate/map gradients (types = node index, :71) when every encoding
+ * of the batch is one-hot.  row_type[rows] in [0, C), C < 32, C < ldo; W, ld multiples of 4; out has ldo columns per w;
+ * accumulate != 0 adds to out instead of setting it; part: scratch of at least W * C floats (more scratch = more row
+ * chunks in flight). */
+int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, int ldo,
+                      int accumulate, float* part, size_t part_floats, void* stream);
 /* test surface (no counterpart in the reference): which kernels score add_edge's pairs (dvae_model.py:210-220) for
  * graphs of up to N nodes at add_edge width EHP (dvae_dims.EHP).  Bits: 1 forward on the LDS-sliced scorer, 2 with more
  * than one window of candidate rows, 4 backward fused per graph (accumulators on chip), 8 backward windowed one-pass;

@@ -401,11 +401,14 @@ def test_small_gemm(cuda, M, G, HP, K, km, acc):
     assert torch.equal(C[M:], C0[M:])
 
 
-@pytest.mark.parametrize("rows,W,C,ld_pad", [(28672, 2048, 8, 0), (1000, 1024, 10, 64), (37, 64, 1, 0), (5000, 3072, 31, 0),
-                                             (0, 256, 8, 0), (513, 2048, 17, 0)])
-def test_typed_colsum(cuda, rows, W, C, ld_pad):
-    """Per-type column sums (the decoder's DTT = DA^T . [onehot(type) | 1]) against torch: every type count incl. the
-    LDS opt-in sizes (17+ types), a padded leading dimension, a single row chunk, no rows at all."""
+@pytest.mark.parametrize("rows,W,C,ld_pad,ldo,acc", [(28672, 2048, 8, 0, 32, 0), (1000, 1024, 10, 64, 32, 0), (37, 64, 1, 0, 32, 0),
+                                                     (5000, 3072, 31, 0, 32, 1), (0, 256, 8, 0, 32, 0), (513, 2048, 17, 0, 32, 0),
+                                                     (61440, 1536, 8, 0, 32, 1), (4096, 1024, 8, 0, 12, 0), (3, 100, 9, 0, 16, 1),
+                                                     (0, 64, 4, 0, 8, 1)])
+def test_typed_colsum(cuda, rows, W, C, ld_pad, ldo, acc):
+    """Per-type column sums (X^T . [onehot(type) | 1]: the decoder's DTT, the GRU cells' input-weight gradients, the gate/map
+    position columns) against torch: every accumulator count (8 / 16 / 32 registers), a padded leading dimension, a single
+    row chunk, fewer rows than waves, no rows at all, narrow outputs (ldo < 32), set and accumulate."""
     from dvae_amd import engine as E
     from dvae_amd._lib import load
     lib = load()
@@ -413,13 +416,20 @@ def test_typed_colsum(cuda, rows, W, C, ld_pad):
     ld = W + ld_pad
     X = torch.randn(max(rows, 1), ld, device=cuda)
     t = torch.randint(0, C, (max(rows, 1),), device=cuda, dtype=torch.int32)
-    out = torch.full((W, 32), float("nan"), device=cuda)
+    before = torch.randn(W, ldo, device=cuda) if acc else torch.full((W, ldo), float("nan"), device=cuda)
+    out = before.clone()
     part = torch.empty(8 << 20, device=cuda)
-    E.check(lib.dvae_typed_colsum(E._ptr(X), ld, rows, W, E._ptr(t), C, E._ptr(out), E._ptr(part), part.numel(), E._stream()))
+    E.check(lib.dvae_typed_colsum(E._ptr(X), ld, rows, W, E._ptr(t), C, E._ptr(out), ldo, acc, E._ptr(part), part.numel(),
+                                  E._stream()))
     torch.cuda.synchronize()
-    onehot = torch.zeros(max(rows, 1), 32, device=cuda, dtype=torch.float64)
+    onehot = torch.zeros(max(rows, 1), ldo, device=cuda, dtype=torch.float64)
     onehot[torch.arange(max(rows, 1), device=cuda), t.long()] = 1.0
     onehot[:, C] = 1.0
     ref = X[:rows, :W].double().t() @ onehot[:rows]
+    if acc:
+        ref = ref + before.double()
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * max(rows, 1) ** 0.5)
-    assert torch.equal(out[:, C + 1:], torch.zeros_like(out[:, C + 1:]))
+    if acc:
+        assert torch.equal(out[:, C + 1:], before[:, C + 1:])          # untouched
+    else:
+        assert torch.equal(out[:, C + 1:], torch.zeros_like(out[:, C + 1:]))
