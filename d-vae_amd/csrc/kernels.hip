@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void typed_colsum_kernel(const float* __restri
   const int col = blockIdx.x * 256 + lane * 4;
   const bool on = col < W;
   const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
-  float4 acc[CT];
+  float4 acc[CT], tot = zero4();   // tot: all rows (the column of ones)
 #pragma unroll
   for (int k = 0; k < CT; ++k) acc[k] = zero4();
   const float* xc = X + (on ? col : 0);
@@ -674,25 +674,32 @@ __global__ __launch_bounds__(256) void typed_colsum_kernel(const float* __restri
     typed_add<CT>(acc, t1, v1);
     typed_add<CT>(acc, t2, v2);
     typed_add<CT>(acc, t3, v3);
+    tot = add4(add4(tot, v0), add4(add4(v1, v2), v3));
   }
   for (; r < r1; r += 4) {
     const int t0 = __builtin_amdgcn_readfirstlane(row_type[r]);
-    typed_add<CT>(acc, t0, on ? ld4(xc + (size_t)r * ld) : zero4());
+    const float4 v0 = on ? ld4(xc + (size_t)r * ld) : zero4();
+    typed_add<CT>(acc, t0, v0);
+    tot = add4(tot, v0);
   }
+  // part[chunk][t][w], t = C: the total
+  float* pc = part + (size_t)blockIdx.y * (C + 1) * W + col;
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
     if (t < C) {   // uniform
       if (wave) sh[wave - 1][lane] = acc[t];
       __syncthreads();
-      if (wave == 0 && on)
-        st4(part + ((size_t)blockIdx.y * C + t) * W + col, add4(add4(acc[t], sh[0][lane]), add4(sh[1][lane], sh[2][lane])));
+      if (wave == 0 && on) st4(pc + (size_t)t * W, add4(add4(acc[t], sh[0][lane]), add4(sh[1][lane], sh[2][lane])));
       __syncthreads();
     }
   }
+  if (wave) sh[wave - 1][lane] = tot;
+  __syncthreads();
+  if (wave == 0 && on) st4(pc + (size_t)C * W, add4(add4(tot, sh[0][lane]), add4(sh[1][lane], sh[2][lane])));
 }
 
-// out[w][c] (+)= sum over chunks of part[chunk][c][w] for c < C, out[w][C] (+)= the sum over all types (every row has
-// exactly one type: the column of ones of the one-hot table), the other columns of the ldo are zero (set, not added).
+// out[w][c] (+)= sum over chunks of part[chunk][c][w] for c <= C (row C of a chunk: all rows, the column of ones of the
+// one-hot table); the other columns of the ldo are zero (set, not added: a launch that accumulates has no blocks for them).
 // Block (x, c): 16 float4 of w for output column c, sixteen lanes per sum over the chunks (four loads in flight each),
 // folded in lane order.
 __global__ __launch_bounds__(256) void typed_colsum_final_kernel(const float* __restrict__ part, int nch, int C, int W,
@@ -703,18 +710,15 @@ __global__ __launch_bounds__(256) void typed_colsum_final_kernel(const float* __
   const bool on = w < W;
   float4 s = zero4();
   if (on && c <= C) {
-    const int t0 = c < C ? c : 0, t1 = c < C ? c + 1 : C;
-    const size_t kstep = (size_t)C * W;
-    for (int t = t0; t < t1; ++t) {
-      const float* q = part + (size_t)t * W + w;
-      int k = kl;
-      for (; k + 48 < nch; k += 64) {
-        const float4 a0 = ld4(q + k * kstep), a1 = ld4(q + (k + 16) * kstep), a2 = ld4(q + (k + 32) * kstep),
-                     a3 = ld4(q + (k + 48) * kstep);
-        s = add4(add4(s, a0), add4(add4(a1, a2), a3));
-      }
-      for (; k < nch; k += 16) s = add4(s, ld4(q + k * kstep));
+    const size_t kstep = (size_t)(C + 1) * W;
+    const float* q = part + (size_t)c * W + w;
+    int k = kl;
+    for (; k + 48 < nch; k += 64) {
+      const float4 a0 = ld4(q + k * kstep), a1 = ld4(q + (k + 16) * kstep), a2 = ld4(q + (k + 32) * kstep),
+                   a3 = ld4(q + (k + 48) * kstep);
+      s = add4(add4(s, a0), add4(add4(a1, a2), a3));
     }
+    for (; k < nch; k += 16) s = add4(s, ld4(q + k * kstep));
   }
   sh[kl][wq] = s;
   __syncthreads();
@@ -1636,17 +1640,17 @@ int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type,
     if (!accumulate) DVAE_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)W * ldo * 4, st));
     return DVAE_OK;
   }
-  DVAE_REQUIRE(part_floats >= (size_t)W * C, "typed_colsum: scratch too small");
+  DVAE_REQUIRE(part_floats >= (size_t)W * (C + 1), "typed_colsum: scratch too small");
   const int gx = cdiv(W, 256);
-  int nch = std::max(1, std::min(cdiv(1024, gx), cdiv(rows, 64)));
-  nch = (int)std::max<size_t>(1, std::min<size_t>(nch, part_floats / ((size_t)W * C)));
+  int nch = std::max(1, std::min(cdiv(768, gx), cdiv(rows, 64)));
+  nch = (int)std::max<size_t>(1, std::min<size_t>(nch, part_floats / ((size_t)W * (C + 1))));
   const int rpc = std::max(1, cdiv(rows, nch));
   nch = std::max(1, cdiv(rows, rpc));
   if (C <= 8) hipLaunchKernelGGL(typed_colsum_kernel<8>, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, row_type, C, part);
   else if (C <= 16) hipLaunchKernelGGL(typed_colsum_kernel<16>, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, row_type, C, part);
   else hipLaunchKernelGGL(typed_colsum_kernel<32>, dim3(gx, nch), dim3(256), 0, st, X, ld, rows, rpc, W, row_type, C, part);
   DVAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 64), ldo), dim3(256), 0, st, part, nch, C, W, out, ldo, accumulate);
+  hipLaunchKernelGGL(typed_colsum_final_kernel, dim3(cdiv(W, 64), accumulate ? C + 1 : ldo), dim3(256), 0, st, part, nch, C, W, out, ldo, accumulate);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }

@@ -301,7 +301,7 @@ int dvae_small_rows_tune(int rows);
  * streaming pass.  The same kernel forms the GRU cells' input-weight / bias gradients (X = dgh, types = node types,
  * dvae_model.py:83,244) and the position columns of the gate/map gradients (types = node index, :71) when every encoding
  * of the batch is one-hot.  row_type[rows] in [0, C), C < 32, C < ldo; W, ld multiples of 4; out has ldo columns per w;
- * accumulate != 0 adds to out instead of setting it; part: scratch of at least W * C floats (more scratch = more row
+ * accumulate != 0 adds to out instead of setting it; part: scratch of at least W * (C + 1) floats (more scratch = more row
  * chunks in flight). */
 int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, int ldo,
                       int accumulate, float* part, size_t part_floats, void* stream);
