@@ -1458,6 +1458,99 @@ __global__ __launch_bounds__(256) void pair_bwd_win_kernel(SchedView sv, TypeSha
   if (threadIdx.x == 0) st4(out + 2 * EHP, make_float4(db, 0.f, 0.f, 0.f));
 }
 
+// The same work items for graphs of at most 8 nodes: ONE window holds every candidate (Bq[j] and dL/dBq[j] of j = 0..6 in
+// registers), so a node's prefix rows are walked once, in order -- row k of node i carries the pairs (i, j) with
+// u_{k+1} <= j < u_k (u_0 = i, u_1 > u_2 > .. the predecessors, u_{deg+1} = 0) -- and the NEXT row that will be visited
+// is known before the current one is processed: its A row is loaded one row ahead (the one-row-at-a-time walk left one
+// 16-byte load in flight per thread; the kernel was bound by that latency, 3.2 TB/s).  Every dL/dA row is stored exactly
+// once (zeros for the rows no pair is scored on).
+__global__ __launch_bounds__(256) void pair_bwd_n8_kernel(SchedView sv, TypeShare ts, int R, int EHP, int G,
+                                                          const int* __restrict__ sizes, const float* __restrict__ A,
+                                                          const float* __restrict__ Bq, const float* __restrict__ Cq,
+                                                          const float* __restrict__ w2, const float* __restrict__ d_edge,
+                                                          float* __restrict__ DA, float* __restrict__ DBq,
+                                                          float* __restrict__ part) {
+  constexpr int W = 7;   // candidates 0 .. 6 (the last node of a graph is never one)
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N, B = sv.B;
+  const int cg = blockIdx.x % G;
+  const int col = cg * 1024 + threadIdx.x * 4;
+  const float4 wv = ld4(w2 + col);
+  float4 dw = zero4(), dbs = zero4();
+  float db = 0.f;
+  for (long long w = blockIdx.x; w < (long long)B * G; w += gridDim.x) {
+    const int b = (int)(w / G);
+    const int n = graph_size(sizes, b, N);
+    if (n <= 0) continue;
+    const float4 c = Cq ? ld4(Cq + (size_t)b * EHP + col) : zero4();
+    float4 bq[W], dj[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      dj[j] = zero4();
+      bq[j] = j + 1 < n ? ld4(Bq + (size_t)S.node2row[b * N + j] * EHP + col) : zero4();
+    }
+    // row (0, 0) has no pair; the walk starts at node 1 with its row 0 already on the way
+    st4(DA + (size_t)prow_of(S, R, S.node2row[b * N], 0) * EHP + col, zero4());
+    {   // node 0's edge rows do not exist (it has no predecessor); nothing else to clear
+    }
+    int r = n > 1 ? S.node2row[b * N + 1] : 0;
+    float4 a_nxt = n > 1 ? ld4(a_row(sv, ts, A, EHP, R, r, 0) + col) : zero4();
+    for (int i = 1; i < n; ++i) {
+      const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+      const int r_next = i + 1 < n ? S.node2row[b * N + i + 1] : 0;
+      const float* de = d_edge + ((size_t)b * N + i) * N;
+      int hi = i - 1;
+      int lo = deg > 0 ? S.row_node[S.csr_idx[p]] : 0;          // lowest candidate of row 0
+      bool have = true;                                          // row 0 of a node i >= 1 always carries pair (i, i-1)
+      for (int k = 0; k <= deg; ++k) {
+        const float4 a = add4(a_nxt, c);
+        // the next row that some pair is scored on: (i, k+1) unless its range is empty, else (i+1, 0)
+        const int lo2 = k + 1 < deg ? S.row_node[S.csr_idx[p + k + 1]] : 0;
+        const bool have2 = k < deg && lo - 1 >= lo2;
+        if (have2) a_nxt = ld4(A + ((size_t)R + p + k) * EHP + col);            // prow(r, k+1) = R + csr_ptr[r] + k
+        else if (k == deg && i + 1 < n) a_nxt = ld4(a_row(sv, ts, A, EHP, R, r_next, 0) + col);
+        float4 da = zero4();
+        if (have) {
+#pragma unroll
+          for (int j = W - 1; j >= 0; --j) {
+            if (j > hi || j < lo) continue;
+            const float ds = de[j];
+            const float4 x = add4(a, bq[j]);
+#define PN_LANE(f)                                   \
+            if (x.f > 0.f) {                           \
+              const float u = ds * wv.f;               \
+              da.f += u;                               \
+              dj[j].f += u;                            \
+              dw.f = fmaf(ds, x.f, dw.f);              \
+            }
+            PN_LANE(x) PN_LANE(y) PN_LANE(z) PN_LANE(w)
+#undef PN_LANE
+            if (cg == 0) db += ds;
+          }
+        }
+        st4(DA + (size_t)prow_of(S, R, r, k) * EHP + col, da);
+        hi = lo - 1;
+        lo = lo2;
+        have = have2;
+      }
+      r = r_next;
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (j + 1 < n) {
+        st4(DBq + (size_t)S.node2row[b * N + j] * EHP + col, dj[j]);
+        dbs = add4(dbs, dj[j]);
+      }
+    st4(DBq + (size_t)S.node2row[b * N + n - 1] * EHP + col, zero4());   // never a candidate (dvae_model.py:210)
+  }
+  float* out = part + (size_t)blockIdx.x * (2 * EHP + 4);
+  for (int g = 0; g < EHP / 1024; ++g) {
+    st4(out + g * 1024 + threadIdx.x * 4, g == cg ? dbs : zero4());
+    st4(out + EHP + g * 1024 + threadIdx.x * 4, g == cg ? dw : zero4());
+  }
+  if (threadIdx.x == 0) st4(out + 2 * EHP, make_float4(db, 0.f, 0.f, 0.f));
+}
+
 #define VPL_DISPATCH(EHP, CALL)                                                   \
   switch ((EHP) / 256) {                                                          \
     case 1: { constexpr int V = 1; CALL; } break;                                 \
@@ -1776,9 +1869,13 @@ int k_pair_bwd_a(const SchedView& sv, const TypeShare& ts, int R, int RH, const 
   return reduce_parts_2stage(part, grid * 4, per, part + used, part_floats - used, out, per, st);
 }
 
+bool pair_bwd_win_ok(int EHP);
 // true when k_pair_bwd_fused covers this shape (the DBq accumulators of a graph fit in 64 KB of LDS)
 bool pair_bwd_fused_ok(int N, int EHP) {
   static const bool off = getenv("DVAE_NO_PAIR_FUSE") != nullptr;   // A-B tests
+  // graphs of up to 8 nodes at whole groups of 1024 columns take pair_bwd_n8_kernel (k_pair_bwd_win) instead
+  static const bool n8_off = getenv("DVAE_PAIR_FUSED_N8") != nullptr;   // A-B tests: the per-graph kernel there, too
+  if (N <= 8 && EHP % 1024 == 0 && !n8_off && pair_bwd_win_ok(EHP)) return false;
   return !off && (EHP == 2048 || EHP == 1024 || EHP == 3072) && (N <= 8 || (size_t)N * EHP * sizeof(float) <= 65536);
 }
 
@@ -1830,12 +1927,16 @@ int k_pair_bwd_win(const SchedView& sv, const TypeShare& ts, int R, const int* s
   const int G = EHP / 1024;
   const size_t per = (size_t)2 * EHP + 4;   // [db1 | dw2 | db2], contiguous in the packed gradient too
   static const int cap = getenv("DVAE_PAIR_WIN_GRID") ? atoi(getenv("DVAE_PAIR_WIN_GRID")) : 2048;   // lab
-  long long grid = std::min<long long>((long long)sv.B * G, cap);
+  long long grid = std::min<long long>((long long)sv.B * G, (sv.N <= 8 && !getenv("DVAE_PAIR_WIN_GRID")) ? 1024 : cap);   // n8: 768 .. 1536 measure alike
   grid = std::min<long long>(grid, (long long)(part_floats / per * 32 / 33));   // room for the 2-stage reduction's group sums
   grid = grid / G * G;                       // a block keeps one column group
   DVAE_REQUIRE(grid >= G, "pair_bwd_win: scratch too small");
   static const int win = getenv("DVAE_PAIR_WIN") ? atoi(getenv("DVAE_PAIR_WIN")) : 8;   // lab: candidates per window (8: 119 VGPRs, 16: 185; same-box c3 129.6 vs 131.5 ms)
-  if (win == 8)
+  static const bool no_n8 = getenv("DVAE_NO_PAIR_N8") != nullptr;   // A-B tests
+  if (sv.N <= 8 && !no_n8)
+    hipLaunchKernelGGL(pair_bwd_n8_kernel, dim3((unsigned)grid), dim3(256), 0, st, sv, ts, R, EHP, G, sizes, A, Bq, Cq, w2,
+                       d_edge, DA, DBq, part);
+  else if (win == 8)
     hipLaunchKernelGGL((pair_bwd_win_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, sv, ts, R, EHP, G, sizes, A, Bq, Cq,
                        w2, d_edge, DA, DBq, part);
   else
