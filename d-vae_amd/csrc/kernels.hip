@@ -1490,9 +1490,7 @@ __global__ __launch_bounds__(256) void pair_bwd_n8_kernel(SchedView sv, TypeShar
       bq[j] = j + 1 < n ? ld4(Bq + (size_t)S.node2row[b * N + j] * EHP + col) : zero4();
     }
     // row (0, 0) has no pair; the walk starts at node 1 with its row 0 already on the way
-    st4(DA + (size_t)prow_of(S, R, S.node2row[b * N], 0) * EHP + col, zero4());
-    {   // node 0's edge rows do not exist (it has no predecessor); nothing else to clear
-    }
+    st4(DA + (size_t)prow_of(S, R, S.node2row[b * N], 0) * EHP + col, zero4());   // (node 0 has no predecessor: no edge rows)
     int r = n > 1 ? S.node2row[b * N + 1] : 0;
     float4 a_nxt = n > 1 ? ld4(a_row(sv, ts, A, EHP, R, r, 0) + col) : zero4();
     for (int i = 1; i < n; ++i) {
