@@ -1458,6 +1458,159 @@ __global__ __launch_bounds__(256) void pair_bwd_win_kernel(SchedView sv, TypeSha
   if (threadIdx.x == 0) st4(out + 2 * EHP, make_float4(db, 0.f, 0.f, 0.f));
 }
 
+// predecessor-mask helpers (SchedView::rowbits: bit u of a node's 128-bit mask set <=> u is a predecessor)
+struct PredMask { uint32_t w[DVAE_BITW]; };
+__device__ __forceinline__ PredMask pred_mask(const SchedView& sv, int b, int N, int i) {
+  PredMask m;
+  const uint4 v = *reinterpret_cast<const uint4*>(sv.rowbits + ((size_t)b * N + i) * DVAE_BITW);
+  m.w[0] = v.x; m.w[1] = v.y; m.w[2] = v.z; m.w[3] = v.w;
+  return m;
+}
+// number of predecessors with index above x (x >= -1)
+__device__ __forceinline__ int preds_above(const PredMask& m, int x) {
+  int c = 0;
+#pragma unroll
+  for (int w = 0; w < DVAE_BITW; ++w) {
+    const int lo = x + 1 - 32 * w;                      // first bit of word w that counts
+    const uint32_t keep = lo <= 0 ? ~0u : lo >= 32 ? 0u : (~0u << lo);
+    c += __popc(m.w[w] & keep);
+  }
+  return c;
+}
+// highest predecessor index <= x, or -1
+__device__ __forceinline__ int pred_at_or_below(const PredMask& m, int x) {
+  int best = -1;
+#pragma unroll
+  for (int w = 0; w < DVAE_BITW; ++w) {
+    const int hi = x - 32 * w;                          // last bit of word w that counts
+    const uint32_t keep = hi < 0 ? 0u : hi >= 31 ? ~0u : ((2u << hi) - 1u);
+    const uint32_t v = m.w[w] & keep;
+    if (v) best = 32 * w + 31 - __clz(v);
+  }
+  return best;
+}
+
+// pair_bwd_win_kernel with the walk driven by the predecessor MASK instead of the CSR lists (no dependent index loads
+// between a node's rows) and with every load issued one step ahead: the next visited row's A (of this node, or the
+// first row the next node meets in this window), the old dL/dA of a row that an earlier window has started, the next
+// node's row index / CSR offset / mask.  Row k of node i carries the candidates [u_{k+1}, u_k - 1] (u_0 = i, u_1 > u_2
+// > .. the predecessors, none left: 0); within the window [jb, jb + WIN) that is [max(u_{k+1}, jb), min(u_k, jb + WIN) - 1].
+template <int WIN>
+__global__ __launch_bounds__(256) void pair_bwd_win2_kernel(SchedView sv, TypeShare ts, int R, int EHP, int G,
+                                                            const int* __restrict__ sizes, const float* __restrict__ A,
+                                                            const float* __restrict__ Bq, const float* __restrict__ Cq,
+                                                            const float* __restrict__ w2, const float* __restrict__ d_edge,
+                                                            float* __restrict__ DA, float* __restrict__ DBq,
+                                                            float* __restrict__ part) {
+  const SchedDir& S = sv.dir[0];
+  const int N = sv.N, B = sv.B;
+  const int cg = blockIdx.x % G;
+  const int col = cg * 1024 + threadIdx.x * 4;
+  const float4 wv = ld4(w2 + col);
+  float4 dw = zero4(), dbs = zero4();
+  float db = 0.f;
+  for (long long w = blockIdx.x; w < (long long)B * G; w += gridDim.x) {
+    const int b = (int)(w / G);
+    const int n = graph_size(sizes, b, N);
+    const float4 c = Cq ? ld4(Cq + (size_t)b * EHP + col) : zero4();
+    // rows that no pair is scored on: node 0's row, and a full prefix whose lowest predecessor is node 0
+    for (int i = 0; i < n; ++i) {
+      const int r = S.node2row[b * N + i];
+      const PredMask m = pred_mask(sv, b, N, i);
+      if (i == 0) st4(DA + (size_t)prow_of(S, R, r, 0) * EHP + col, zero4());
+      else if (m.w[0] & 1u) st4(DA + (size_t)prow_of(S, R, r, preds_above(m, -1)) * EHP + col, zero4());
+    }
+    for (int jb = 0; jb + 1 < n; jb += WIN) {
+      float4 bq[WIN], dj[WIN];
+#pragma unroll
+      for (int jj = 0; jj < WIN; ++jj) {
+        dj[jj] = zero4();
+        const int j = jb + jj;
+        bq[jj] = j < n ? ld4(Bq + (size_t)S.node2row[b * N + j] * EHP + col) : zero4();
+      }
+      // node jb + 1: its row index, CSR offset, mask, and the first row it meets in this window
+      int r = S.node2row[b * N + jb + 1];
+      int p = S.csr_ptr[r];
+      PredMask m = pred_mask(sv, b, N, jb + 1);
+      int k = preds_above(m, jb);                       // jtop = min(jb + WIN, jb + 1) - 1 = jb
+      float4 a_nxt = ld4(a_row(sv, ts, A, EHP, R, r, k) + col);
+      for (int i = jb + 1; i < n; ++i) {
+        const float* de = d_edge + ((size_t)b * N + i) * N;
+        // the next node's bookkeeping is on the way while this node's rows are processed
+        int r2 = 0, p2 = 0;
+        PredMask m2 = m;
+        if (i + 1 < n) {
+          r2 = S.node2row[b * N + i + 1];
+          m2 = pred_mask(sv, b, N, i + 1);
+        }
+        int hi = min(jb + WIN, i) - 1;
+        for (;;) {
+          const int u = pred_at_or_below(m, hi);        // lowest candidate of the row overall (none: node 0)
+          const int lo_full = u < 0 ? 0 : u;
+          const int lo = max(lo_full, jb);
+          const bool first = lo_full >= jb;              // no earlier (lower) window has met this row
+          const bool more = u > jb;                      // the node's next row meets this window too (u >= 0 then)
+          float* dst = DA + (size_t)prow_of(S, R, r, k) * EHP + col;
+          const float4 a = add4(a_nxt, c);
+          float4 old = zero4();
+          if (!first) old = ld4(dst);
+          if (more) {
+            a_nxt = ld4(A + ((size_t)R + p + k) * EHP + col);                    // prow(r, k + 1)
+          } else if (i + 1 < n) {
+            p2 = S.csr_ptr[r2];
+            a_nxt = ld4(a_row(sv, ts, A, EHP, R, r2, preds_above(m2, min(jb + WIN, i + 1) - 1)) + col);
+          }
+          float4 da = zero4();
+#pragma unroll
+          for (int jj = WIN - 1; jj >= 0; --jj) {
+            const int j = jb + jj;
+            if (j > hi || j < lo) continue;
+            const float ds = de[j];
+            const float4 x = add4(a, bq[jj]);
+#define PW2_LANE(f)                                  \
+            if (x.f > 0.f) {                           \
+              const float uu = ds * wv.f;              \
+              da.f += uu;                              \
+              dj[jj].f += uu;                          \
+              dw.f = fmaf(ds, x.f, dw.f);              \
+            }
+            PW2_LANE(x) PW2_LANE(y) PW2_LANE(z) PW2_LANE(w)
+#undef PW2_LANE
+            if (cg == 0) db += ds;
+          }
+          st4(dst, first ? da : add4(old, da));
+          if (!more) break;
+          hi = u - 1;
+          ++k;
+        }
+        if (i + 1 < n) {
+          r = r2; p = p2; m = m2;
+          k = preds_above(m, min(jb + WIN, i + 1) - 1);
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < WIN; ++jj) {
+        const int j = jb + jj;
+        if (j < n) {
+          st4(DBq + (size_t)S.node2row[b * N + j] * EHP + col, dj[jj]);
+          dbs = add4(dbs, dj[jj]);
+        }
+      }
+    }
+    if (n >= 1 && ((n - 1) % WIN) == 0) {
+      // the last node opens no window of its own when n-1 is a multiple of WIN: it is never a candidate
+      // (dvae_model.py:210), its dL/dBq row is zero
+      st4(DBq + (size_t)S.node2row[b * N + n - 1] * EHP + col, zero4());
+    }
+  }
+  float* out = part + (size_t)blockIdx.x * (2 * EHP + 4);
+  for (int g = 0; g < EHP / 1024; ++g) {
+    st4(out + g * 1024 + threadIdx.x * 4, g == cg ? dbs : zero4());
+    st4(out + EHP + g * 1024 + threadIdx.x * 4, g == cg ? dw : zero4());
+  }
+  if (threadIdx.x == 0) st4(out + 2 * EHP, make_float4(db, 0.f, 0.f, 0.f));
+}
+
 // The same work items for graphs of at most 8 nodes: ONE window holds every candidate (Bq[j] and dL/dBq[j] of j = 0..6 in
 // registers), so a node's prefix rows are walked once, in order -- row k of node i carries the pairs (i, j) with
 // u_{k+1} <= j < u_k (u_0 = i, u_1 > u_2 > .. the predecessors, u_{deg+1} = 0) -- and the NEXT row that will be visited
@@ -1934,6 +2087,9 @@ int k_pair_bwd_win(const SchedView& sv, const TypeShare& ts, int R, const int* s
   if (sv.N <= 8 && !no_n8)
     hipLaunchKernelGGL(pair_bwd_n8_kernel, dim3((unsigned)grid), dim3(256), 0, st, sv, ts, R, EHP, G, sizes, A, Bq, Cq, w2,
                        d_edge, DA, DBq, part);
+  else if (win == 8 && !getenv("DVAE_PAIR_WIN_OLD"))   // (DVAE_PAIR_WIN_OLD: the CSR-driven walk, A-B tests)
+    hipLaunchKernelGGL((pair_bwd_win2_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, sv, ts, R, EHP, G, sizes, A, Bq, Cq,
+                       w2, d_edge, DA, DBq, part);
   else if (win == 8)
     hipLaunchKernelGGL((pair_bwd_win_kernel<8>), dim3((unsigned)grid), dim3(256), 0, st, sv, ts, R, EHP, G, sizes, A, Bq, Cq,
                        w2, d_edge, DA, DBq, part);
