@@ -281,6 +281,8 @@ def main():
                     help="lab: the decoder's Adam as an instance of its own, stepped on the side stream as soon as its "
                          "gradients are final (under the encoder's backward); measured 0.07-0.1 ms SLOWER than one "
                          "fused Adam after the step at B = 512 ... 4096, so it is not the default")
+    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"],
+                    help="Adam(lr=1e-4) of the train step: dvae_amd.optim.FlatAdam (one launch per module) or torch's fused Adam")
     ap.add_argument("--no-core-ab", action="store_true", help="N = 1: skip the few steps on the fp32-MFMA GEMM core after the timed region")
     ap.add_argument("--no-weak-probe", action="store_true", help="N > 1: skip the fixed-per-GPU-batch probe after the timed region")
     ap.add_argument("--dry-run", action="store_true",
@@ -362,7 +364,10 @@ def main():
             return e, t
     else:
         # Adam(lr=1e-4) on every parameter each step (dvae_model.py:471-475): one fused instance
-        if not args.split_optimizer:
+        if args.optimizer == "flat" and not args.split_optimizer:
+            # the same Adam update as ONE launch per module over flat buffers (dvae_adam_step, optim.FlatAdam)
+            opt, opt_dec = dvae_amd.optim.FlatAdam(model, lr=1e-4), None
+        elif not args.split_optimizer:
             opt, opt_dec = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True), None
         else:
             opt = torch.optim.Adam(model.encoder.parameters(), lr=1e-4, fused=True)
@@ -506,6 +511,8 @@ def main():
             res["config"]["report"] = {k: (round(float(v), 6) if isinstance(v, (int, float)) else v) for k, v in report.items()}
         if cfg["kind"] == "train":
             res["config"]["final_loss"] = final
+            res["config"]["optimizer"] = ("Adam(lr=1e-4), dvae_amd.optim.FlatAdam (torch.optim.Adam's update, one launch per module)"
+                                          if args.optimizer == "flat" and not args.split_optimizer else "torch.optim.Adam(lr=1e-4, fused=True)")
             last = getattr(model, "_step_keep", None)
             if last is not None:
                 # the encoder's forward sweep runs on one row per distinct node VALUE (index, type, predecessor values) of the

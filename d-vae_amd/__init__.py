@@ -6,4 +6,4 @@ directory name is not a Python identifier).
 from .metrics import reconstruction_accuracy  # noqa: F401
 from .model import Decoder, Dvae, Encoder  # noqa: F401
 from .svae import Svae  # noqa: F401
-from . import svae, synth  # noqa: F401
+from . import optim, svae, synth  # noqa: F401

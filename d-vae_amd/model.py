@@ -259,8 +259,15 @@ class Dvae(nn.Module):
             metrics = {k: torch.stack([o[k] for o in outputs]).mean() for k in keys}
         return {'avg_val_loss': metrics['val_loss'], 'log': metrics}
 
-    def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.parameters(), lr=1e-4)
+    def configure_optimizers(self, flat=False):
+        """dvae_model.py:471-475: Adam(lr=1e-4) + ReduceLROnPlateau.  ``flat=True``: the same update as one HIP launch
+        per module over flat buffers (optim.FlatAdam: a torch Optimizer with torch Adam's state_dict layout); models
+        whose modules share parameters (same_mapper_gater) keep torch's."""
+        if flat and not self._shared_gm and next(self.parameters()).is_cuda:
+            from .optim import FlatAdam
+            optimizer = FlatAdam(self, lr=1e-4)
+        else:
+            optimizer = torch.optim.Adam(self.parameters(), lr=1e-4)
         lr_schedule = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer)
         return [optimizer], [lr_schedule]
 

@@ -60,6 +60,8 @@ class Trainer:
     fused             use `model.loss_and_grad` (forward + hand-written backward, gradients written
                       straight into flat buffers) when the model has it; else
                       `training_step(...)['loss'].backward()` through autograd
+    flat_adam         with `fused`: the model's Adam as one launch per module over flat buffers (optim.FlatAdam; same
+                      update, same checkpoint layout as torch.optim.Adam) when `configure_optimizers` offers it
     dist              torch.distributed module (initialised) for data-parallel runs: every rank
                       trains on its shard of each batch, gradients are SUM all-reduced (dp.py)
     A batch dict may carry 'eps' [B,Z]: the reparameterisation draw per GLOBAL graph index (sharded with the
@@ -67,8 +69,9 @@ class Trainer:
     """
 
     def __init__(self, max_epochs=300, save_dir=None, fused=True, dist=None, keep_all=False, log=print,
-                 max_steps_per_epoch=None):
+                 max_steps_per_epoch=None, flat_adam=True):
         self.max_epochs, self.save_dir, self.fused, self.dist = int(max_epochs), save_dir, fused, dist
+        self.flat_adam = flat_adam
         self.keep_all, self.log, self.max_steps = keep_all, log, max_steps_per_epoch
         self.history = []
         self.epoch = 0
@@ -82,7 +85,9 @@ class Trainer:
 
     def fit(self, model, resume_from=None):
         from . import dp
-        (opt,), (sched,) = model.configure_optimizers()
+        import inspect
+        flat = self.flat_adam and self.fused and 'flat' in inspect.signature(model.configure_optimizers).parameters
+        (opt,), (sched,) = model.configure_optimizers(flat=True) if flat else model.configure_optimizers()
         if resume_from:
             self.epoch = load_checkpoint(resume_from, model, opt, sched).get('epoch', -1) + 1
         dev = self._device(model)

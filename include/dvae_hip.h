@@ -305,6 +305,14 @@ int dvae_small_rows_tune(int rows);
  * chunks in flight). */
 int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type, int C, float* out, int ldo,
                       int accumulate, float* part, size_t part_floats, void* stream);
+/* The optimizer of the train step: torch.optim.Adam's update (dvae_model.py:471-475 configure_optimizers, Adam(lr=1e-4);
+ * no amsgrad, weight_decay folded into the gradient as torch does) over a FLAT fp32 buffer of n parameters in one
+ * streaming pass: g' = g + wd p; m += (1 - beta1)(g' - m); v = beta2 v + (1 - beta2) g'^2;
+ * p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).  step counts from 1.  All four buffers
+ * 16-byte aligned, device memory; grad is not modified.  (dvae_amd.optim.FlatAdam keeps a model's parameters, both
+ * moments and the flat gradients of Dvae.loss_and_grad in such buffers.) */
+int dvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, long long step, void* stream);
 /* test surface (no counterpart in the reference): which kernels score add_edge's pairs (dvae_model.py:210-220) for
  * graphs of up to N nodes at add_edge width EHP (dvae_dims.EHP).  Bits: 1 forward on the LDS-sliced scorer, 2 with more
  * than one window of candidate rows, 4 backward fused per graph (accumulators on chip), 8 backward windowed one-pass;
