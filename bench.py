@@ -39,7 +39,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16, v_mfma_f32_3
 # its roof in fp32-equivalent FLOP/s is the bf16 peak / 6
 PEAK_X6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E
-PROF_EVERY = 4                   # timed steps between two steps whose GEMM launches carry HIP events
+PROF_EVERY = 8                   # timed steps between two steps whose GEMM launches carry HIP events (4 in runs of fewer than 16 steps)
 
 # BASELINE.json `configs` (c1..c5) + the headline shape of `metric`
 CONFIGS = {
@@ -407,9 +407,10 @@ def main():
     # event records around each of ~110 launches cost 0.44 ms on a 12.4 ms step when every step has them
     prof = not args.no_profile and world == 1
     prof_steps = 0
+    prof_every = PROF_EVERY if args.steps >= 16 else 4
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = prof and i % PROF_EVERY == 0
+        sample = prof and i % prof_every == 0
         if sample:
             lib.dvae_gemm_profile(2 if prof_steps else 1)
             prof_steps += 1
@@ -565,7 +566,7 @@ def main():
                 "note": "HIP events around every launch of the kernel on every %d-th timed step; launches run on "
                         "two streams and overlap: achieved = algorithmic FLOPs / wall time with at least one "
                         "launch of the kernel running; avg_launch_us is the plain per-launch mean; "
-                        "executed_tflops counts the FLOPs the launches really did" % PROF_EVERY,
+                        "executed_tflops counts the FLOPs the launches really did" % prof_every,
                 "algorithmic_gflop_per_dag": per_dag / 1e9,
             }
             # HBM bytes of the dominant kernel from the kept counter pass (rocprofv3 --pmc, separate passes, FETCH_SIZE
