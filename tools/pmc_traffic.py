@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(name, counter):
-    f = glob.glob(os.path.join(ROOT, 'gpurun_out/pmc_%s_%s/*/*counter_collection.csv' % (tag, name)))[0]
+    # (gpurun merges each call's files into gpurun_out/ without removing older ones: take the newest pass)
+    f = max(glob.glob(os.path.join(ROOT, 'gpurun_out/pmc_%s_%s/*/*counter_collection.csv' % (tag, name))), key=os.path.getmtime)
     by, calls, seen = collections.defaultdict(float), collections.Counter(), set()
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter:
