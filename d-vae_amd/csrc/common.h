@@ -94,3 +94,6 @@ struct KernelProf {
 
 // loss.hip: resolve dvae_elbo_static's per-device array address on the current device (set-up time)
 int elbo_static_warm();
+// d_mu += d_z, d_logvar += d_z . eps . 0.5 exp(0.5 logvar): dvae_reparam_bwd and the two additions behind it in one launch
+int k_reparam_bwd_acc(const float* d_z, const float* logvar, const float* eps, float* d_mu, float* d_logvar, long long n,
+                      hipStream_t st);

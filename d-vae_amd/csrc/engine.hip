@@ -704,8 +704,12 @@ extern "C" int dvae_encoder_fwd(const dvae_dims* dp, const float* x, const int* 
   // mu | logvar heads (dvae_model.py:121-122)
   DVAE_TRY(g.nt(w.HVF, HP, P + L.Wml, HP, w.ML, 2 * d.ZP, B, 2 * d.ZP, HP, P + L.bml));
   if (hv) DVAE_TRY(k_unpad_rows(w.HVF, HP, B, d.H, hv, st));
-  if (mu) DVAE_TRY(k_unpad_rows(w.ML, 2 * d.ZP, B, d.Z, mu, st));
-  if (logvar) DVAE_TRY(k_unpad_rows(w.ML + d.ZP, 2 * d.ZP, B, d.Z, logvar, st));
+  if (mu && logvar) {
+    DVAE_TRY(k_unpad_rows2(w.ML, 2 * d.ZP, d.ZP, B, d.Z, mu, logvar, st));
+  } else {
+    if (mu) DVAE_TRY(k_unpad_rows(w.ML, 2 * d.ZP, B, d.Z, mu, st));
+    if (logvar) DVAE_TRY(k_unpad_rows(w.ML + d.ZP, 2 * d.ZP, B, d.Z, logvar, st));
+  }
   if (states && shared) {
     DVAE_TRY(k_nodes_to_dense(Sf, B, d.N, w.f.Hn, HP, states, d.H, st));
   } else if (states) {
@@ -739,8 +743,7 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
   const int HP = d.HP, B = d.B, ZP = d.ZP;
 
   // heads
-  DVAE_TRY(k_pad_rows(d_mu, B, d.Z, w.DML, 2 * ZP, ZP, st));
-  DVAE_TRY(k_pad_rows(d_logvar, B, d.Z, w.DML + ZP, 2 * ZP, ZP, st));
+  DVAE_TRY(k_pad_rows2(d_mu, d_logvar, B, d.Z, w.DML, 2 * ZP, ZP, st));
   DVAE_TRY(ev.edge(st, sd));
   DVAE_TRY(gs.tn(w.DML, 2 * ZP, w.HVF, HP, Gp + L.Wml, HP, 2 * ZP, HP, B));
   DVAE_TRY(k_colsum(w.DML, 2 * ZP, B, 2 * ZP, Gp + L.bml, ssc.part, ssc.part_floats, sd));
@@ -1147,10 +1150,12 @@ extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stre
   const long long nz = (long long)dd.B * dd.Z;
   // packed gradient buffers start at zero; the decoder's weights are packed on the side stream, they are
   // not needed before the encoder is through
-  DVAE_TRY(k_zero(s->Ge, dvae_enc_grad_floats(&de) * sizeof(float), st));
-  DVAE_TRY(k_zero(s->Gd, dvae_dec_grad_floats(&dd) * sizeof(float), st));
+  // (on the side stream: every write to Ge / Gd but the pair scorer's bias sums is queued there, and the chain meets the
+  // side stream again before the decoder starts)
   DVAE_TRY(dvae_pack_params(s->enc_table, s->enc_n, s->Pe, st));
   DVAE_TRY(ev.edge(st, sd));
+  DVAE_TRY(k_zero(s->Ge, dvae_enc_grad_floats(&de) * sizeof(float), sd));
+  DVAE_TRY(k_zero(s->Gd, dvae_dec_grad_floats(&dd) * sizeof(float), sd));
   DVAE_TRY(dvae_pack_params(s->dec_table, s->dec_n, s->Pd, sd));
   DVAE_TRY(dvae_encoder_fwd(&de, s->x, s->sizes, s->sched, s->info_host, s->Pe, s->ws_enc, nullptr, w.mu, w.logvar,
                             nullptr, nullptr, st));
@@ -1162,9 +1167,7 @@ extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stre
                      w.elbo_part, w.d_edge, w.d_type, w.d_mu, w.d_logvar, st));
   DVAE_TRY(dvae_decoder_bwd(&dd, w.z, s->x, s->sizes, s->sched, s->info_host, s->Pd, s->ws_dec, w.d_edge, w.d_type,
                             s->Gd, w.d_z, st, side_stream));
-  DVAE_TRY(dvae_reparam_bwd(w.d_z, w.logvar, s->eps, w.dmu2, w.dlv2, nz, st));
-  DVAE_TRY(k_add_rows(w.d_mu, dd.Z, w.dmu2, dd.Z, dd.B, dd.Z, st));
-  DVAE_TRY(k_add_rows(w.d_logvar, dd.Z, w.dlv2, dd.Z, dd.B, dd.Z, st));
+  DVAE_TRY(k_reparam_bwd_acc(w.d_z, w.logvar, s->eps, w.d_mu, w.d_logvar, nz, st));
   return DVAE_OK;
 }
 

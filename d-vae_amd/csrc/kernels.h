@@ -114,6 +114,9 @@ int k_typed_colsum(const float* X, int ld, int rows, int W, const int* row_type,
                    size_t part_floats, hipStream_t st, int ldo = 32, int accumulate = 0);
 
 // [B][N][W] API tensors <-> node-row tables
+// two [rows][W] tables into the halves of one padded row / back out of them (the mu | logvar heads): one launch each
+int k_pad_rows2(const float* in0, const float* in1, int rows, int W, float* out, int ld, int ncols, hipStream_t st);
+int k_unpad_rows2(const float* in, int ld, int off, int rows, int W, float* out0, float* out1, hipStream_t st);
 int k_rows_to_dense(const SchedDir& S, int R, const float* T, int ld, float* out, int N, int W, hipStream_t st);
 // the same through node2row: out[b][i][:W] = T[row of node (b,i)] (0 for absent nodes); for schedules whose rows
 // stand for several nodes (SchedView::enc)

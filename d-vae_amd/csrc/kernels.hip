@@ -858,6 +858,29 @@ __global__ void pad_rows_kernel(const float* __restrict__ in, int rows, int W, f
   }
 }
 
+// two tables side by side in one padded row: out[r][0:ncols] <- in0[r][0:W] | 0, out[r][ncols:2 ncols] <- in1[r][0:W] | 0
+__global__ void pad_rows2_kernel(const float* __restrict__ in0, const float* __restrict__ in1, int rows, int W,
+                                 float* __restrict__ out, int ld, int ncols) {
+  const long long total = (long long)rows * 2 * ncols;
+  ITEM_LOOP(total) {
+    const int r = (int)(it / (2 * ncols)), cc = (int)(it % (2 * ncols));
+    const int h = cc >= ncols, c = cc - h * ncols;
+    const float* in = h ? in1 : in0;
+    out[(size_t)r * ld + cc] = (in && c < W) ? in[(size_t)r * W + c] : 0.f;   // a missing table reads as zeros
+  }
+}
+// and back: out0[r][0:W] <- in[r][0:W], out1[r][0:W] <- in[r][off:off+W]
+__global__ void unpad_rows2_kernel(const float* __restrict__ in, int ld, int off, int rows, int W, float* __restrict__ out0,
+                                   float* __restrict__ out1) {
+  const long long total = (long long)rows * 2 * W;
+  ITEM_LOOP(total) {
+    const int h = it >= (long long)rows * W;
+    const long long k = it - (h ? (long long)rows * W : 0);
+    const int r = (int)(k / W), c = (int)(k % W);
+    (h ? out1 : out0)[k] = in[(size_t)r * ld + h * off + c];
+  }
+}
+
 __global__ void relu_bwd_kernel(float* __restrict__ d, const float* __restrict__ y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     if (!(y[i] > 0.f)) d[i] = 0.f;
@@ -2141,6 +2164,21 @@ int k_pad_rows(const float* in, int rows, int W, float* out, int ld, int ncols, 
   if (rows <= 0) return DVAE_OK;
   hipLaunchKernelGGL(pad_rows_kernel, grid_for((long long)rows * ncols), dim3(256), 0, st, in, rows, W, out, ld,
                      ncols);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_pad_rows2(const float* in0, const float* in1, int rows, int W, float* out, int ld, int ncols, hipStream_t st) {
+  if (rows <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(pad_rows2_kernel, grid_for((long long)rows * 2 * ncols), dim3(256), 0, st, in0, in1, rows, W, out, ld,
+                     ncols);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_unpad_rows2(const float* in, int ld, int off, int rows, int W, float* out0, float* out1, hipStream_t st) {
+  if (rows <= 0) return DVAE_OK;
+  hipLaunchKernelGGL(unpad_rows2_kernel, grid_for((long long)rows * 2 * W), dim3(256), 0, st, in, ld, off, rows, W, out0, out1);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }

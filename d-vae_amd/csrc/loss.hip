@@ -56,6 +56,20 @@ __global__ void reparam_bwd_kernel(const float* __restrict__ dz, const float* __
   }
 }
 
+// the same, ADDED to the gradients the ELBO left in dmu / dlogvar: reparam_bwd_kernel + two row additions in one launch
+// (same operations in the same order: products rounded before the sum, so the bits are those of the three launches)
+__global__ void reparam_bwd_acc_kernel(const float* __restrict__ dz, const float* __restrict__ logvar,
+                                       const float* __restrict__ eps, float* __restrict__ dmu,
+                                       float* __restrict__ dlogvar, long long n) {
+#pragma clang fp contract(off)   // the product below must round before it is added, as it does between the separate launches
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float g = dz[i];
+    const float t = g * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+    dmu[i] = dmu[i] + g;
+    dlogvar[i] = dlogvar[i] + t;
+  }
+}
+
 // one wave per graph; partial[b] = {edge, vertex, kl}
 __global__ __launch_bounds__(64) void elbo_kernel(dvae_dims d, const float* __restrict__ el,
                                                   const float* __restrict__ tl, const float* __restrict__ g,
@@ -161,6 +175,15 @@ extern "C" int dvae_reparam_bwd(const float* d_z, const float* logvar, const flo
   const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_z, logvar, eps, d_mu,
                      d_logvar, n);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_reparam_bwd_acc(const float* d_z, const float* logvar, const float* eps, float* d_mu, float* d_logvar, long long n,
+                      hipStream_t st) {
+  if (n <= 0) return DVAE_OK;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(reparam_bwd_acc_kernel, dim3(grid), dim3(256), 0, st, d_z, logvar, eps, d_mu, d_logvar, n);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
