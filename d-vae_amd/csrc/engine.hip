@@ -18,6 +18,22 @@
 namespace {
 
 
+// lab: DVAE_PHASES=1 records a timing event on the chain at a dozen phase boundaries of the fused step (what the chain
+// waits for, and where); dvae_phase_read() returns the times since the first mark.  Off: nothing is created or recorded.
+struct Phases {
+  bool on = getenv("DVAE_PHASES") != nullptr;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> tag;
+};
+Phases g_phases;
+void phase_mark(int tag, hipStream_t st) {
+  if (!g_phases.on) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, st) != hipSuccess) return;
+  g_phases.ev.push_back(e);
+  g_phases.tag.push_back(tag);
+}
+
 struct LevelCfg {
   int fused_gm_min_rows; int fused_gru; int type_share;
   int node_hidden = getenv("DVAE_NO_NODE_HIDDEN") ? 0 : 1;   // prefix sweeps: one hidden product per node (SweepBufs::PG)
@@ -544,7 +560,10 @@ struct WgradOut { float *Ggru, *Ggm, *Xgru, *Xgm; };
 // column sums per type / per position (k_typed_colsum: one streaming pass at 3.5-5 TB/s instead of a [3HP x 32] tile grid
 // that walks the table at 1.3) and the tables themselves are never built
 int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const float* x,
-                const WgradOut& o, bool seeded, const G& g, const TypeGrad* tg, int La, int Lb, bool first, bool onehot) {
+                const WgradOut& o, bool seeded, const G& g, const TypeGrad* tg, int La, int Lb, bool first, bool onehot,
+                int which = 3) {
+  // which: 1 = the GRU cell's gradients, 2 = the gate/map network's (mod None: the two halves share no table, so the tail
+  // of a step can run them on two streams), 3 = both
   const int HP = d.HP, PP = pos_cols(d), R = lv.R;
   hipStream_t st = g.st;
   const int RH = R > 0 ? b.RH : 0;
@@ -556,9 +575,11 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
   static const bool typed_off = getenv("DVAE_NO_TYPED_WGRAD") != nullptr;   // A-B tests: the TN products
   const bool typed = onehot && !typed_off && g.part != nullptr;
   const bool typed_pos = typed && d.mod == 0 && d.npos < 32 && d.npos < PP;   // position one-hot: at most 31 positions
-  if (first) {
+  if (first && (which & 1)) {
     if (typed) DVAE_TRY(k_build_xt(S, b.prefix, RH, x, d.N, d.C, b.XT, st));
     else DVAE_TRY(k_build_xp(S, b.prefix, RH, x, d.N, d.C, b.XP, st));
+  }
+  if (first && (which & 2)) {
     if (d.mod == 0 && !typed_pos) DVAE_TRY(k_build_px(S, Rg, d.npos, PP, b.PX, st));
     else if (d.mod != 0 && !typed) DVAE_TRY(k_build_xp(S, 0, R, x, d.N, d.C, b.PX, st));
   }
@@ -574,7 +595,9 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
     return g.tn(b.GHN + (size_t)r0 * HP, HP, b.XP + (size_t)r0 * 32, 32, Xn, 32, HP, 32, r1 - r0, a);
   };
   const int n0 = R > 0 ? lv.ls[La] : 0, n1 = R > 0 ? lv.ls[Lb] : 0;   // node rows of the chunk
-  if (!b.prefix) {
+  if (!(which & 1)) {
+    // (the GRU half runs elsewhere)
+  } else if (!b.prefix) {
     // dWhh = dgh^T . h_in over the rows whose h_in is not identically zero (level 0 of a node sweep has h_in = 0)
     const int r0 = d.mod == 0 ? std::max(n0, z1) : n0;
     DVAE_TRY(g.tn(b.GH + (size_t)r0 * 3 * HP, 3 * HP, b.AGG + (size_t)r0 * HP, HP, o.Ggru, HP, 3 * HP, HP, n1 - r0, acc));
@@ -600,6 +623,7 @@ int sweep_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBu
       }
     }
   }
+  if (!(which & 2)) return DVAE_OK;
   if (d.mod == 0) {
     const int r1 = std::min(n1, Rg);
     DVAE_TRY(g.tn(b.GMP + (size_t)n0 * 2 * HP, 2 * HP, b.Hn + (size_t)n0 * HP, HP, o.Ggm, HP, 2 * HP, HP, r1 - n0, acc));
@@ -643,7 +667,7 @@ int wgrad_split_level(const dvae_dims& d, const Levels& lv, bool prefix, bool tw
 // backward sweep on the chain + its weight-gradient products on the side stream
 int sweep_bwd_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
                     const float* x, const WgradOut& o, bool seeded, const G& g, const G& gs, Events& ev, bool onehot,
-                    bool k0_shared = false, const TypeGrad* tg = nullptr) {
+                    bool k0_shared = false, const TypeGrad* tg = nullptr, const G* tail_chain = nullptr) {
   const int L0 = wgrad_split_level(d, lv, b.prefix, g.st != gs.st);
   bool early = false;
   std::function<int(int)> after = [&](int L) -> int {
@@ -654,6 +678,16 @@ int sweep_bwd_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, Swe
   };
   DVAE_TRY(sweep_bwd(d, S, lv, b, w, seeded, g, k0_shared, after));
   DVAE_TRY(ev.edge(g.st, gs.st));
+  // tail_chain (the LAST sweep of a step, node sweeps, mod None): nothing is left for the chain but to wait for these
+  // products, so it takes the gate/map half itself; the side stream then waits for it (G is complete when the side
+  // stream has drained, as documented).  For small batches, whose products cannot fill the card one at a time: B = 512 -1.4 %.
+  static const bool split_tail = getenv("DVAE_NO_TAIL_SPLIT") == nullptr;
+  if (tail_chain && split_tail && tail_chain->st != gs.st && d.mod == 0 && !b.prefix) {
+    const int Lend = early ? L0 : lv.nlev;
+    DVAE_TRY(sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, 0, Lend, !early, onehot, 1));
+    DVAE_TRY(sweep_wgrad(d, S, lv, b, x, o, seeded, *tail_chain, tg, 0, Lend, !early, onehot, 2));
+    return ev.edge(tail_chain->st, gs.st);
+  }
   return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, 0, early ? L0 : lv.nlev, !early, onehot);
 }
 
@@ -784,8 +818,10 @@ extern "C" int dvae_encoder_bwd(const dvae_dims* dp, const float* x, const int* 
   } else {
     DVAE_TRY(k_take_last_bwd(Sf, sizes, B, d.N, w.DHVF, w.f.DH, HP, st));
   }
+  const G gtail{w.sc[0].gemm_ws, st, 0, 0, w.sc[0].part, w.sc[0].part_floats};   // the chain's half of the last products
   DVAE_TRY(sweep_bwd_wgrad(d, Sf, lfs, w.f, wf, x,
-                           WgradOut{Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f}, false, g, gs, ev, info[5] == 1));
+                           WgradOut{Gp + L.gru_f, Gp + L.gm_f, Gp + L.xg_gru_f, Gp + L.xg_gm_f}, false, g, gs, ev, info[5] == 1,
+                           false, nullptr, &gtail));
   return DVAE_OK;
 }
 
@@ -856,10 +892,12 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     return DVAE_OK;
   };
   DVAE_TRY(sweep_fwd(d, S, lv, w.s, sw, x, w.H0, g, hook, typed));
+  phase_mark(2, st);
 
   // pair scores need every A / Bq row: the chain waits for the side stream's products here
   DVAE_CHECK_HIP(hipMemsetAsync(edge_logits, 0, (size_t)B * d.N * d.N * 4, st));
   DVAE_TRY(ev.edge(sd, st));
+  phase_mark(3, st);
   // add_vertex on the graph state seen before each node (dvae_model.py:199-200,251-257): MFMA
   // work on the side stream, beside the bandwidth-bound pair scorer on the chain
   // (DVAE_AV_MAIN=1 keeps it on the chain: A-B tests)
@@ -880,7 +918,9 @@ extern "C" int dvae_decoder_fwd(const dvae_dims* dp, const float* z, const float
     KernelProf kp(4, pair_bytes(d, lv), st);
     DVAE_TRY(k_pair_fwd(sv, ts, R, sizes, w.A, w.Bq, w.Cq, P + L.w2, P + L.b2, edge_logits, EHP, st));
   }
+  phase_mark(4, st);
   DVAE_TRY(ev.edge(sd, st));
+  phase_mark(5, st);
   return DVAE_OK;
 }
 
@@ -959,6 +999,7 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   }
   }
   if (d.mod) DVAE_TRY(k_graph_sum(S, sizes, B, d.N, w.DBq, EHP, w.DCq, st));
+  phase_mark(7, st);
   // the add_edge weight-gradient products (side stream).  Lab switch: issue them AFTER the chain's own
   // add_edge input-gradient products, so that those two -- the largest launches on the chain (B=512: 219 +
   // 80 us beside the side stream's products, 111 + 40 us alone) -- run alone.  Measured neutral (B=512: 2.613
@@ -1028,9 +1069,11 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
   DVAE_TRY(k_graph_state_bwd(S, R, B, d.N, d.mod, sizes, w.DGS, w.s.DHn, w.DH0, HP, st));
   DVAE_TRY(g.nn(w.DBq, EHP, P + L.W1b, HP, w.s.DHn, HP, Rb, HP, EHP, 1));
   if (defer_side) DVAE_TRY(side_products());
+  phase_mark(8, st);
   const TypeGrad tgrad{w.TG, w.TGN, w.XPT};
   DVAE_TRY(sweep_bwd_wgrad(d, S, lv, w.s, sw, x, WgradOut{Gp + L.gru, Gp + L.gm, Gp + L.xg_gru, Gp + L.xg_gm}, true,
                            g, gs, ev, info[5] == 1, typed, typed ? &tgrad : nullptr));
+  phase_mark(9, st);
   DVAE_TRY(k_add_dh0(S, B, d.N, w.s.DH, w.DH0, HP, st));
   if (d.mod) DVAE_TRY(g.nn(w.DCq, EHP, P + L.W1c, HP, w.DH0, HP, B, HP, EHP, 1));
 
@@ -1147,6 +1190,7 @@ extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stre
   hipStream_t sd = side_stream ? (hipStream_t)side_stream : st;
   Events& ev = g_events;
   const StepWs w = step_ws(dd, s->ws_step);
+  phase_mark(0, st);
   const long long nz = (long long)dd.B * dd.Z;
   // packed gradient buffers start at zero; the decoder's weights are packed on the side stream, they are
   // not needed before the encoder is through
@@ -1160,14 +1204,17 @@ extern "C" int dvae_step_part1(const dvae_step* s, void* stream, void* side_stre
   DVAE_TRY(dvae_encoder_fwd(&de, s->x, s->sizes, s->sched, s->info_host, s->Pe, s->ws_enc, nullptr, w.mu, w.logvar,
                             nullptr, nullptr, st));
   DVAE_TRY(dvae_reparam_fwd(w.mu, w.logvar, s->eps, w.z, nz, st));
+  phase_mark(1, st);
   DVAE_TRY(ev.edge(sd, st));
   DVAE_TRY(dvae_decoder_fwd(&dd, w.z, s->x, s->sizes, s->sched, s->info_host, s->Pd, s->ws_dec, w.edge_logits,
                             w.type_logits, nullptr, st, side_stream));
   DVAE_TRY(dvae_elbo(&dd, w.edge_logits, w.type_logits, s->g, s->x, s->sizes, w.mu, w.logvar, s->beta, s->out4,
                      w.elbo_part, w.d_edge, w.d_type, w.d_mu, w.d_logvar, st));
+  phase_mark(6, st);
   DVAE_TRY(dvae_decoder_bwd(&dd, w.z, s->x, s->sizes, s->sched, s->info_host, s->Pd, s->ws_dec, w.d_edge, w.d_type,
                             s->Gd, w.d_z, st, side_stream));
   DVAE_TRY(k_reparam_bwd_acc(w.d_z, w.logvar, s->eps, w.d_mu, w.d_logvar, nz, st));
+  phase_mark(10, st);
   return DVAE_OK;
 }
 
@@ -1176,6 +1223,29 @@ extern "C" int dvae_step_part2(const dvae_step* s, void* stream, void* side_stre
                "step_part2: null pointer");
   DVAE_TRY(step_dims_ok(*s->d_enc, *s->d_dec));
   const StepWs w = step_ws(*s->d_dec, s->ws_step);
-  return dvae_encoder_bwd(s->d_enc, s->x, s->sizes, s->sched, s->info_host, s->Pe, s->ws_enc, nullptr, w.d_mu,
-                          w.d_logvar, s->Ge, stream, side_stream);
+  const int rc = dvae_encoder_bwd(s->d_enc, s->x, s->sizes, s->sched, s->info_host, s->Pe, s->ws_enc, nullptr, w.d_mu,
+                                  w.d_logvar, s->Ge, stream, side_stream);
+  phase_mark(11, (hipStream_t)stream);
+  if (g_phases.on && side_stream) {   // ... and when the side stream is through with the step's last weight gradient
+    g_events.edge((hipStream_t)side_stream, (hipStream_t)stream);
+    phase_mark(12, (hipStream_t)stream);
+  }
+  return rc;
+}
+
+// lab (DVAE_PHASES=1): waits for the device, then out_ms[i] = time of mark i since the first mark, tags[i] = its tag;
+// returns the number of marks (at most max) and forgets them
+extern "C" int dvae_phase_read(double* out_ms, int* tags, int max) {
+  DVAE_CHECK_HIP(hipDeviceSynchronize());
+  const int n = (int)std::min<size_t>(g_phases.ev.size(), (size_t)std::max(max, 0));
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    DVAE_CHECK_HIP(hipEventElapsedTime(&ms, g_phases.ev[0], g_phases.ev[i]));
+    out_ms[i] = ms;
+    tags[i] = g_phases.tag[i];
+  }
+  for (hipEvent_t e : g_phases.ev) (void)hipEventDestroy(e);
+  g_phases.ev.clear();
+  g_phases.tag.clear();
+  return n;
 }

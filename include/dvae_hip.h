@@ -313,6 +313,13 @@ int dvae_typed_colsum(const float* X, int ld, int rows, int W, const int* row_ty
  * moments and the flat gradients of Dvae.loss_and_grad in such buffers.) */
 int dvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                    double beta2, double eps, double weight_decay, long long step, void* stream);
+/* lab (no counterpart in the reference): with DVAE_PHASES=1 in the environment the fused step records a timing event on
+ * the caller's stream at a dozen phase boundaries (0 start, 1 encoder forward done, 2 decoder sweep done, 3 side stream's
+ * add_edge products joined, 4 pairs scored, 5 add_vertex joined, 6 ELBO done, 7 pair backward done, 8 add_edge input
+ * gradients done, 9 decoder backward sweep done, 10 end of part 1, 11 encoder backward's chain done, 12 side stream
+ * joined).  dvae_phase_read waits for the device, returns the marks' times in ms since the first one and their tags
+ * (at most max), and forgets them.  tools/lab/phases.py prints the per-phase means. */
+int dvae_phase_read(double* out_ms, int* tags, int max);
 /* test surface (no counterpart in the reference): which kernels score add_edge's pairs (dvae_model.py:210-220) for
  * graphs of up to N nodes at add_edge width EHP (dvae_dims.EHP).  Bits: 1 forward on the LDS-sliced scorer, 2 with more
  * than one window of candidate rows, 4 backward fused per graph (accumulators on chip), 8 backward windowed one-pass;
