@@ -684,6 +684,9 @@ int sweep_bwd_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, Swe
   static const bool split_tail = getenv("DVAE_NO_TAIL_SPLIT") == nullptr;
   if (tail_chain && split_tail && tail_chain->st != gs.st && d.mod == 0 && !b.prefix) {
     const int Lend = early ? L0 : lv.nlev;
+    // the chain's half ACCUMULATES into what the early chunk set on the side stream: it must see those writes (the event
+    // is recorded before the side stream's own half is queued, so the chain waits for nothing newer)
+    if (early) DVAE_TRY(ev.edge(gs.st, tail_chain->st));
     DVAE_TRY(sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, 0, Lend, !early, onehot, 1));
     DVAE_TRY(sweep_wgrad(d, S, lv, b, x, o, seeded, *tail_chain, tg, 0, Lend, !early, onehot, 2));
     return ev.edge(tail_chain->st, gs.st);
