@@ -209,24 +209,34 @@ def test_trainer_fits_real_enas_rows(cuda, tmp_path, fused):
     assert abs(v1 - v2) <= 1e-6 * abs(v1)
 
 
+@pytest.mark.parametrize("shared_rows", [False, True])
 @pytest.mark.parametrize("bidir", [False, True])
-def test_early_weight_gradient_chunk(cuda, bidir):
+def test_early_weight_gradient_chunk(cuda, gemm_core, bidir, shared_rows):
     """Weight-gradient products of the upper levels issued while the backward sweep still runs
     (forced here at a small size; by default only sweeps of >= 16384 rows do it): the gradients
     are those of the single pass after the sweep -- the loss is bit-identical (forward untouched),
-    the gradients differ by the order of two partial sums only."""
+    the gradients differ by the order of two partial sums only.  On both GEMM cores, with and without shared
+    encoder rows: the encoder's last products are split between the two streams behind the early chunk (the chain's
+    half accumulates into what the side stream's early chunk set), and a repeated step must give the same bits."""
+    import os
     from dvae_amd import _lib
     lib = _lib.load()
     model, X, eps = _setup(cuda, 200, bidir=bidir)
+    slots0 = -1 if os.environ.get("DVAE_NO_MERGE") else int(os.environ.get("DVAE_MERGE_MIN", 8192))
     try:
+        lib.dvae_enc_merge_tune(0 if shared_rows else -1)
         lib.dvae_wgrad_split_tune(0.0, 16384)
         ref = _step(model, X, eps)
         lib.dvae_wgrad_split_tune(0.5, 0)
         out = _step(model, X, eps)
+        for _ in range(3):
+            again = _step(model, X, eps)
+            assert torch.equal(again[0], out[0]) and torch.equal(again[1], out[1]), "the step is not reproducible"
         lib.dvae_wgrad_split_tune(0.2, 0)
         out2 = _step(model, X, eps)
     finally:
         lib.dvae_wgrad_split_tune(0.35, 16384)
+        lib.dvae_enc_merge_tune(slots0)
     assert torch.equal(out[0], ref[0]) and torch.equal(out2[0], ref[0])
     for o in (out, out2):
         rel = float((o[1] - ref[1]).norm() / ref[1].norm())
