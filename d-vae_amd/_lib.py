@@ -84,6 +84,7 @@ SIGNATURES = {
     "dvae_level_tune": (c_int, [c_int, c_int, c_int]),
     "dvae_small_rows_tune": (c_int, [c_int]),
     "dvae_enc_merge_tune": (c_int, [c_int]),
+    "dvae_recompute_tune": (c_int, [c_int]),
     "dvae_phase_read": (c_int, [c_void_p, c_void_p, c_int]),
     "dvae_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, ctypes.c_double, ctypes.c_double,
                        ctypes.c_double, ctypes.c_double, ctypes.c_double, c_ll, c_void_p]),

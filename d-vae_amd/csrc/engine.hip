@@ -330,6 +330,15 @@ bool skip_level0(const int* info) { return scored_rows_only() && info[7] == 1; }
 bool node_hidden(const dvae_dims& d, const SweepBufs& b) {
   return g_level_cfg.node_hidden && b.prefix && d.mod == 0 && g_level_cfg.fused_gru != 1;
 }
+// ... and then the backward pass rebuilds the gates of every prefix row from GM / PG instead of reading five saved tables
+// per row (kernels.hip prefix_gru_bwd_kernel); the forward pass writes the states only.  DVAE_NO_RECOMPUTE=1: A-B tests
+// Per level, from 1024 node rows up: below that the row-parallel gru_bwd_kernel fills the card better than a walk per node
+// (B = 512: 2.069 ms against 2.090 with recomputation everywhere; headline 8.28 -> 8.20, c3 101.0 -> 98.3, same box).
+int g_recompute_min_rows = getenv("DVAE_NO_RECOMPUTE") ? -1 : getenv("DVAE_RECOMPUTE_MIN") ? atoi(getenv("DVAE_RECOMPUTE_MIN")) : 1024;
+bool gates_recomputed(const dvae_dims& d, const SweepBufs& b, int level_rows) {
+  static const bool off = getenv("DVAE_PG_SPLIT") != nullptr;
+  return !off && g_recompute_min_rows >= 0 && node_hidden(d, b) && level_rows >= g_recompute_min_rows;
+}
 
 // SURVEY.md 8(d), pair scoring forward: every A row (E + N prefix rows) and every Bq row (N) read once, 16 H bytes each
 // (24 H in bn mode, whose add_edge is 6H wide), one logit written per pair; backward = 2 x.  Pairs counted as for
@@ -420,7 +429,7 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       if (b.prefix) { p0 = R + lv.es[L]; p1 = R + lv.es[L + 1]; }
       if (pg && !split_pg) {                                                                     // aggregation + gates
         KernelProf kp(6, 4.0 * d.H * (lv.level_edges(L) + 2.0 * (p1 - p0)), st);
-        DVAE_TRY(k_prefix_gru_fwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, st));
+        DVAE_TRY(k_prefix_gru_fwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, st, gates_recomputed(d, b, ne - ns) ? 0 : 1));
       }
       else if (pg) DVAE_TRY(k_gru_fwd(S, p0, p1, 0, b, x, d.N, d.C, w.gru, HP, st));              // GH rows summed by k_agg_fwd
       else DVAE_TRY(gru_rows(p0, p1));
@@ -450,7 +459,7 @@ int sweep_fwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
 }
 
 // reverse-level sweep: DH holds dL/dHV on entry, dL/dAGG on exit
-int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w,
+int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs& b, const SweepW& w, const float* x,
               bool seeded, const G& g, bool k0_shared = false,
               const std::function<int(int)>& after_level = nullptr) {
   const int HP = d.HP, R = lv.R;
@@ -538,7 +547,8 @@ int sweep_bwd(const dvae_dims& d, const SchedDir& S, const Levels& lv, SweepBufs
       if (seeded) DVAE_TRY(dagg_gemm(ns, ne));      // only node 0's h_in = h0 needs it
     } else {
       const int p0 = b.prefix ? R + lv.es[L] : ns, p1 = b.prefix ? R + lv.es[L + 1] : ne;
-      if (!gru_done) DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st, &gparts, ns));
+      if (gates_recomputed(d, b, ne - ns)) DVAE_TRY(k_prefix_gru_bwd(S, ns, ne, b, x, d.N, d.C, w.gru, HP, st, &gparts, ns));
+      else if (!gru_done) DVAE_TRY(k_gru_bwd(S, p0, p1, b, HP, st, &gparts, ns));
       if (!pg) DVAE_TRY(dagg_gemm(p0, p1));
     }
     if (after_level) DVAE_TRY(after_level(L));   // levels >= L are final from here on
@@ -676,7 +686,7 @@ int sweep_bwd_wgrad(const dvae_dims& d, const SchedDir& S, const Levels& lv, Swe
     early = true;
     return sweep_wgrad(d, S, lv, b, x, o, seeded, gs, tg, L0, lv.nlev, true, onehot);
   };
-  DVAE_TRY(sweep_bwd(d, S, lv, b, w, seeded, g, k0_shared, after));
+  DVAE_TRY(sweep_bwd(d, S, lv, b, w, x, seeded, g, k0_shared, after));
   DVAE_TRY(ev.edge(g.st, gs.st));
   // tail_chain (the LAST sweep of a step, node sweeps, mod None): nothing is left for the chain but to wait for these
   // products, so it takes the gate/map half itself; the side stream then waits for it (G is complete when the side
@@ -1121,6 +1131,13 @@ extern "C" int dvae_side_stream_destroy(void* stream) {
 extern "C" int dvae_wgrad_split_tune(double frac, int min_rows) {
   g_wgrad_split.frac = frac;
   g_wgrad_split.min_rows = min_rows;
+  return DVAE_OK;
+}
+
+// tuning / test knob: decoder levels of at least `min_rows` node rows rebuild their GRU gates in the backward pass instead of
+// saving them in the forward pass (negative = never).  Set it between steps, not between a forward and its backward.
+extern "C" int dvae_recompute_tune(int min_rows) {
+  g_recompute_min_rows = min_rows;
   return DVAE_OK;
 }
 

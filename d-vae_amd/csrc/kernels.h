@@ -52,7 +52,11 @@ int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float
 // prefix sweeps with PG, levels >= 1: aggregation (running h_in and running Whh.h_in from PG) and the
 // GRUCell epilogue of every edge prefix row of node rows [ns,ne) in one pass
 int k_prefix_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
-                     const GruW& w, int HP, hipStream_t st);
+                     const GruW& w, int HP, hipStream_t st, int save = 1);
+// its backward with the gates REBUILT from GM / PG (for a forward pass run with save = 0): what k_gru_bwd does on the
+// edge rows of node rows [ns,ne), parts as there
+int k_prefix_gru_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C, const GruW& w, int HP,
+                     hipStream_t st, const GemmPartials* parts = nullptr, int parts_row0 = 0);
 // prefix sweeps with PG: DGM[u] = sum of DH over the consumer rows that hold u, PG[u] = the same sum of dgh (GH)
 int k_dgm_gather(const SchedDir& S, int ns, int ne, const SweepBufs& b, int HP, hipStream_t st);
 // ... and, once DGM is complete, through g*m:  GMP <- (dGM*m*g*(1-g), dGM*g)

@@ -163,6 +163,8 @@ __global__ void gru_fwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, in
 // state to the running h_in and its hidden product PG to the running W_hh.h_in, then applies the
 // gates; the input part W_ih.x + b_ih is the node's and is computed once.  Nothing of the running
 // sums goes through memory except the h_in rows the backward pass reads (AGG).
+// SAVE = false: the backward pass recomputes the gates from GM / PG (prefix_gru_bwd_kernel), so only the states are written
+template <bool SAVE>
 __global__ void prefix_gru_fwd_kernel(SchedDir S, int R, int ns, int ne, const float* __restrict__ GM,
                                       const float* __restrict__ PG, float* __restrict__ AGG,
                                       float* __restrict__ GH, float* __restrict__ GHN, float* __restrict__ HV,
@@ -173,7 +175,7 @@ __global__ void prefix_gru_fwd_kernel(SchedDir S, int R, int ns, int ne, const f
   ITEM_LOOP(total) {
     const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
     const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
-    st4(AGG + (size_t)r * HP + j, zero4());     // the node's own (k = 0) row: h_in = 0 at levels >= 1
+    st4(AGG + (size_t)r * HP + j, zero4());     // the node's own (k = 0) row: h_in = 0 at levels >= 1 (its backward reads it)
     if (deg == 0) continue;
     const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
     float4 gi[3];
@@ -205,14 +207,87 @@ __global__ void prefix_gru_fwd_kernel(SchedDir S, int R, int ns, int ne, const f
       PG_LANE(x) PG_LANE(y) PG_LANE(z) PG_LANE(w)
 #undef PG_LANE
       const size_t row = (size_t)R + p + t;
-      st4(AGG + row * HP + j, a);
-      float* gh = GH + row * 3 * HP + j;
-      st4(gh, rr);
-      st4(gh + HP, zz);
-      st4(gh + 2 * HP, nn);
-      st4(GHN + row * HP + j, ghn);
+      if (SAVE) {
+        st4(AGG + row * HP + j, a);
+        float* gh = GH + row * 3 * HP + j;
+        st4(gh, rr);
+        st4(gh + HP, zz);
+        st4(gh + 2 * HP, nn);
+        st4(GHN + row * HP + j, ghn);
+      }
       st4(HV + row * HP + j, hh);
       if (t == deg - 1) st4(Hn + (size_t)r * HP + j, hh);
+    }
+  }
+}
+
+// The backward of prefix_gru_fwd_kernel<false>: the same walk over a node's predecessors rebuilds every prefix row's h_in,
+// hidden product and gates from GM / PG (the same operations in the same order: the same bits as the forward pass had),
+// reads the row's dL/dHV and writes what gru_bwd_kernel writes -- dgh into GH, dn_pre into GHN, dL/dh_in into DH.  The five
+// activation tables per prefix row are never stored: the forward pass writes one table instead of six, this pass reads
+// GM / PG rows that its neighbours share through L2 instead of five private rows.  PG of the predecessors still holds the
+// forward products here: dgm_gather overwrites a level's PG rows only after the levels above it are through.
+__global__ void prefix_gru_bwd_kernel(SchedDir S, int R, int ns, int ne, const float* __restrict__ GM,
+                                      const float* __restrict__ PG, float* __restrict__ GH, float* __restrict__ GHN,
+                                      float* __restrict__ DH, const float* __restrict__ DHn, const float* __restrict__ x,
+                                      int N, int C, GruW w, int HP, GemmPartials parts, int parts_row0) {
+  const int HP4 = HP >> 2;
+  const long long total = (long long)(ne - ns) * HP4;
+  ITEM_LOOP(total) {
+    const int r = ns + (int)(it / HP4), j = (int)(it % HP4) * 4;
+    const int p = S.csr_ptr[r], deg = S.csr_ptr[r + 1] - p;
+    if (deg == 0) continue;
+    const float* xr = x + ((size_t)S.row_graph[r] * N + S.row_node[r]) * C;
+    float4 gi[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gi[g] = ld4(w.bih + g * HP + j);
+    for (int c = 0; c < C; ++c) {
+      const float xv = xr[c];
+      if (xv != 0.f) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gi[g] = fma4(xv, ld4(w.WihT + (size_t)c * 3 * HP + g * HP + j), gi[g]);
+      }
+    }
+    const float4 br = ld4(w.bhh + j), bz = ld4(w.bhh + HP + j), bn = ld4(w.bhh + 2 * HP + j);
+    float4 a = zero4(), g0 = zero4(), g1 = zero4(), g2 = zero4();
+    for (int t = 0; t < deg; ++t) {
+      const size_t u = S.csr_idx[p + t];
+      a = add4(a, ld4(GM + u * HP + j));
+      const float* pu = PG + u * 3 * HP + j;
+      g0 = add4(g0, ld4(pu));
+      g1 = add4(g1, ld4(pu + HP));
+      g2 = add4(g2, ld4(pu + 2 * HP));
+      const float4 ghr = add4(br, g0), ghz = add4(bz, g1), ghn = add4(bn, g2);
+      const size_t row = (size_t)R + p + t;
+      float4 dh = ld4(DH + row * HP + j);
+      if (t == deg - 1) {   // the node's final state also takes the gradient of everything that reads the node (gru_bwd_kernel)
+        float4 e = ld4(DHn + (size_t)r * HP + j);
+        if (parts.slab) {
+          const float* sp = parts.slab + (size_t)(r - parts_row0) * HP + j;
+          float4 sum = zero4();
+          for (int k = 0; k < parts.splits; ++k) sum = add4(sum, ld4(sp + (size_t)k * parts.stride));
+          e = add4(sum, e);
+        }
+        dh = add4(dh, e);
+      }
+      float4 rr, zz, nn, drp, dzp, dnp, dnr, da;
+#define PB_LANE(f)                                              \
+      rr.f = sigm(gi[0].f + ghr.f);                               \
+      zz.f = sigm(gi[1].f + ghz.f);                               \
+      nn.f = tanhf(gi[2].f + rr.f * ghn.f);                       \
+      dnp.f = dh.f * (1.f - zz.f) * (1.f - nn.f * nn.f);          \
+      dzp.f = dh.f * (a.f - nn.f) * zz.f * (1.f - zz.f);          \
+      drp.f = dnp.f * ghn.f * rr.f * (1.f - rr.f);                \
+      dnr.f = dnp.f * rr.f;                                       \
+      da.f = dh.f * zz.f;
+      PB_LANE(x) PB_LANE(y) PB_LANE(z) PB_LANE(w)
+#undef PB_LANE
+      float* gh = GH + row * 3 * HP + j;
+      st4(gh, drp);
+      st4(gh + HP, dzp);
+      st4(gh + 2 * HP, dnr);
+      st4(GHN + row * HP + j, dnp);
+      st4(DH + row * HP + j, da);
     }
   }
 }
@@ -1754,10 +1829,20 @@ int k_agg_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float
 }
 
 int k_prefix_gru_fwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C,
-                     const GruW& w, int HP, hipStream_t st) {
+                     const GruW& w, int HP, hipStream_t st, int save) {
   if (ne <= ns) return DVAE_OK;
-  hipLaunchKernelGGL(prefix_gru_fwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns,
-                     ne, b.GM, b.PG, b.AGG, b.GH, b.GHN, b.HV, b.Hn, x, N, C, w, HP);
+  hipLaunchKernelGGL(save ? prefix_gru_fwd_kernel<true> : prefix_gru_fwd_kernel<false>,
+                     grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns, ne, b.GM, b.PG, b.AGG, b.GH, b.GHN,
+                     b.HV, b.Hn, x, N, C, w, HP);
+  DVAE_LAUNCH_CHECK();
+  return DVAE_OK;
+}
+
+int k_prefix_gru_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, const float* x, int N, int C, const GruW& w, int HP,
+                     hipStream_t st, const GemmPartials* parts, int parts_row0) {
+  if (ne <= ns) return DVAE_OK;
+  hipLaunchKernelGGL(prefix_gru_bwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns, ne, b.GM,
+                     b.PG, b.GH, b.GHN, b.DH, b.DHn, x, N, C, w, HP, parts ? *parts : GemmPartials{nullptr, 1, 0}, parts_row0);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }

@@ -295,6 +295,11 @@ int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share);
  * reduction split over the waves of a workgroup, gates fused into the forward products; default 1024, environment
  * DVAE_SMALL_ROWS); 0 = never.  Same formulas either way (fp32 summation order differs). */
 int dvae_small_rows_tune(int rows);
+/* tuning / test knob: decoder sweep levels (mod None) of at least min_rows node rows do not save the GRU gates of their prefix
+ * rows in the forward pass; the backward pass rebuilds them from the gated states and hidden products it already reads (same
+ * operations in the same order: the same bits).  Default 1024 (DVAE_RECOMPUTE_MIN / DVAE_NO_RECOMPUTE in the environment),
+ * negative = never.  Change it between steps only: a backward pass must see the setting its forward pass ran with. */
+int dvae_recompute_tune(int min_rows);
 /* Per-type column sums (unit-test surface): out32[w][c] = sum over the rows of type c of X[row][w] for c < C, out32[w][C] =
  * the sum over all rows, the other entries of the 32 zero -- the product X^T . [onehot(type) | 1] of the decoder's per-type
  * gradient sums (the backward of Decoder.forward's k = 0 states, dvae_model.py:203-207, shared by node type) as one

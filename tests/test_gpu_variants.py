@@ -209,6 +209,30 @@ def test_trainer_fits_real_enas_rows(cuda, tmp_path, fused):
     assert abs(v1 - v2) <= 1e-6 * abs(v1)
 
 
+@pytest.mark.parametrize("bidir,B,p", [(False, 300, 0.35), (True, 90, 0.6), (False, 40, 0.1)])
+def test_recomputed_gates_are_bit_identical(cuda, gemm_core, bidir, B, p):
+    """Decoder levels that rebuild the GRU gates of their prefix rows in the backward pass (dvae_recompute_tune: by default
+    levels of 1024 node rows or more) against levels that save them in the forward pass: the same operations in the same
+    order, so losses and every gradient agree bit for bit.  Dense and sparse graphs (long and short predecessor lists)."""
+    import os
+    import dvae_amd
+    from dvae_amd import _lib
+    lib = _lib.load()
+    model, X, eps = _setup(cuda, B, bidir=bidir)
+    g, x = dvae_amd.synth.random_dags(B, 8, 8, p, seed=33, chain=True)
+    X = {'graph': g.to(cuda), 'node_encoding': x.to(cuda)}
+    default = -1 if os.environ.get("DVAE_NO_RECOMPUTE") else int(os.environ.get("DVAE_RECOMPUTE_MIN", 1024))
+    try:
+        lib.dvae_recompute_tune(-1)
+        ref = _step(model, X, eps)
+        lib.dvae_recompute_tune(0)
+        out = _step(model, X, eps)
+    finally:
+        lib.dvae_recompute_tune(default)
+    assert torch.equal(out[0], ref[0])
+    assert torch.equal(out[1], ref[1])
+
+
 @pytest.mark.parametrize("shared_rows", [False, True])
 @pytest.mark.parametrize("bidir", [False, True])
 def test_early_weight_gradient_chunk(cuda, gemm_core, bidir, shared_rows):
