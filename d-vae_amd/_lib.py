@@ -77,6 +77,7 @@ SIGNATURES = {
     "dvae_gemm_force_tile": (c_int, [c_int]),
     "dvae_gemm_tune": (c_int, [c_int, c_int]),
     "dvae_gemm_variant": (c_int, [c_int]),
+    "dvae_gemm_pf": (c_int, [c_int]),
     "dvae_gemm_x6": (c_int, [c_int]),
     "dvae_gemm_core": (c_int, []),
     "dvae_gemm_force_splits": (c_int, [c_int]),

@@ -37,8 +37,22 @@ static int g_mid_split = getenv("DVAE_NO_MID_SPLIT") ? 0 : 1;   // A-B knob for 
 extern "C" int dvae_gemm_force_splits(int v) { g_force_splits = v; return 0; }
 static int g_dbg = 0;
 extern "C" int dvae_gemm_dbg(int v) { g_dbg = v; return 0; }
-static int g_variant = 0;           // lab knob: 0 default (k-tile 16), 3 k-tile 32
+static int g_variant = 0;           // lab knob (fp32-MFMA core): 0 default (k-tile 16), 3 k-tile 32
+// x6 core, prefetch form of the 64x64 / 64x128 / 128x128 kernels: -1 by shape (pf_of below), 0 / 1 / 2 forced (A-B tests)
+static int g_pf = getenv("DVAE_GEMM_PF") ? atoi(getenv("DVAE_GEMM_PF")) : -1;
 extern "C" int dvae_gemm_variant(int v) { g_variant = v; return 0; }
+extern "C" int dvae_gemm_pf(int v) { g_pf = v; return 0; }
+// tools/bench_gemm_pf.py, same box: the compiler weaves the next tile's split arithmetic into this tile's MFMA stream and
+// waits for the loads it has only just issued after the FIRST product.  Holding the split behind the products
+// (sched_barrier) gains 1.5-3 % on the large NT / NN shapes; two k-tiles in flight gain 11-16 % on the 4096-row NN products
+// (64x64 tiles, latency-bound: 119 -> 132 TF at K = 1536) and 5 % on the NT ones; the weight-gradient (TN) shapes lose 3-5 %
+// with either and keep the plain form.
+static inline int pf_of(int a_kmajor, int b_kmajor, bool quarter) {
+  if (g_pf >= 0) return g_pf;
+  if (a_kmajor) return 0;
+  (void)b_kmajor;
+  return quarter ? 2 : 1;
+}
 
 namespace {
 
@@ -330,8 +344,9 @@ __global__ __launch_bounds__(512, 1) void gemm_wsk_kernel(GemmParams p) {
   store_tile<TM, TN>(acc, p, p.C, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2, bool KG = false, bool X6 = false>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2, bool KG = false, bool X6 = false, int PF = 0>
 __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
+  static_assert(PF == 0 || (!KG && ST == 1), "deeper prefetch: plain operands, one LDS stage");
   static_assert(!KG || (AKM == 1 && BKM == 1), "a gathered reduction needs two k-major operands");
   static_assert(!X6 || BK == 32, "the x6 core stages 32-wide k-tiles");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -433,22 +448,46 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
     }
     }
   };
-  auto refill = [&]() {   // registers -> LDS for the next k-tile
+  auto refill_from = [&](const TA& a, const TB& b) {   // registers -> LDS for the next k-tile
     if (ST == 1) {
       __syncthreads();
-      ta.store(lds, tid);
-      tb.store(lds + TA::LDS_FLOATS, tid);
+      a.store(lds, tid);
+      b.store(lds + TA::LDS_FLOATS, tid);
       __syncthreads();
     } else {
       float* nx = lds + (cur ^ 1) * STAGE;
-      ta.store(nx, tid);
-      tb.store(nx + TA::LDS_FLOATS, tid);
+      a.store(nx, tid);
+      b.store(nx + TA::LDS_FLOATS, tid);
       __syncthreads();
       cur ^= 1;
     }
   };
+  auto refill = [&]() { refill_from(ta, tb); };
 
   int k0 = kb;
+  if constexpr (PF == 2) {
+    // two k-tiles in flight: the tile staged after this one's products was loaded a whole iteration ago, so the split
+    // arithmetic the compiler weaves into the MFMA stream never waits for memory
+    if (k0 + 2 * BK <= ke) {
+      TA ta2 = ta;
+      TB tb2 = tb;
+      ta.template load<false>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
+      tb.template load<false>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
+      for (; k0 + 4 * BK <= ke; k0 += 2 * BK) {
+        ta2.template load<false>(p.A, p.lda, m0, p.M, k0 + 2 * BK, ke, tid);
+        tb2.template load<false>(p.B, p.ldb, n0, p.N, k0 + 2 * BK, ke, tid);
+        compute();
+        refill_from(ta, tb);
+        ta.template load<false>(p.A, p.lda, m0, p.M, k0 + 3 * BK, ke, tid);
+        tb.template load<false>(p.B, p.ldb, n0, p.N, k0 + 3 * BK, ke, tid);
+        compute();
+        refill_from(ta2, tb2);
+      }
+      compute();
+      refill_from(ta, tb);
+      k0 += BK;
+    }
+  }
   // hot loop: the next k-tile is a full one, loaded without predicates or branches (a loop
   // body with both load forms makes the compiler wait for the loads where the forms merge)
   for (; k0 + 2 * BK <= ke; k0 += BK) {
@@ -462,6 +501,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
       tb.template load<false>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
     }
     compute();
+    if constexpr (PF == 1) __builtin_amdgcn_sched_barrier(0);   // the next tile's split stays behind this tile's products
     refill();
   }
   // the last one or two k-tiles (a ragged reduction ends in a partial tile)
@@ -557,7 +597,7 @@ void gemm_prof_end(void* h, hipStream_t st) { prof_end(static_cast<GemmProf*>(h)
 
 namespace {
 
-template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1, int MINB = 2, bool KG = false, bool X6 = false>
+template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK = 32, int ST = 1, int MINB = 2, bool KG = false, bool X6 = false, int PF = 0>
 int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   GemmParams p;
   p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias;
@@ -605,7 +645,7 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
     p.c_split = 0;
   }
   GemmProf* pr = prof_begin(AKM * 2 + BKM, 2.0 * d.M * d.N * d.K, stream);
-  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST, MINB, KG, X6>), dim3(p.nblk, splits), dim3(256),
+  hipLaunchKernelGGL((gemm_f32_kernel<AKM, BKM, BM, BN, WM, WN, BK, ST, MINB, KG, X6, PF>), dim3(p.nblk, splits), dim3(256),
                      0, stream, p);
   prof_end(pr, stream);
   DVAE_LAUNCH_CHECK();
@@ -718,6 +758,13 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
   if (g_x6) {                                                                                \
     if (narrow) return launch<AK, BKK, 128, 32, 4, 1, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);   \
     if (flat) return launch<AK, BKK, 32, 128, 1, 4, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);     \
+    /* prefetch form (pf_of): 1 = the next tile's split held behind this tile's products, 2 = two k-tiles in flight */ \
+    const int pf = pf_of(AK, BKK, quarter);                                                  \
+    if (pf) {                                                                                \
+      if (quarter) return pf == 1 ? launch<AK, BKK, 64, 64, 2, 2, 32, 1, 2, false, true, 1>(d, ws, ws_bytes, stream) : launch<AK, BKK, 64, 64, 2, 2, 32, 1, 2, false, true, 2>(d, ws, ws_bytes, stream);   \
+      if (half) return pf == 1 ? launch<AK, BKK, 64, 128, 1, 4, 32, 1, 2, false, true, 1>(d, ws, ws_bytes, stream) : launch<AK, BKK, 64, 128, 1, 4, 32, 1, 2, false, true, 2>(d, ws, ws_bytes, stream);   \
+      return pf == 1 ? launch<AK, BKK, 128, 128, 2, 2, 32, 1, 2, false, true, 1>(d, ws, ws_bytes, stream) : launch<AK, BKK, 128, 128, 2, 2, 32, 1, 2, false, true, 2>(d, ws, ws_bytes, stream);   \
+    }                                                                                        \
     if (quarter) return launch<AK, BKK, 64, 64, 2, 2, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);   \
     return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 1, 2, false, true>(d, ws, ws_bytes, stream)         \
                 : launch<AK, BKK, 128, 128, 2, 2, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);       \

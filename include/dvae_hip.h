@@ -96,6 +96,8 @@ int dvae_small_gemm(const float* A, int lda, const float* W, int ldw, int w_kmaj
 int dvae_gemm_force_tile(int mode);   /* tuning knob: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
 int dvae_gemm_force_splits(int v);     /* lab knob: split-K factor of every launch (0 = automatic) */
 int dvae_gemm_variant(int v);          /* lab knob: force a tile shape (0 = automatic) */
+int dvae_gemm_pf(int v);               /* A-B knob, x6 core: prefetch form of the GEMM main loop (-1 by shape, 0 plain, 1 split held behind the
+                                          products, 2 two k-tiles in flight); results are bit-identical across the forms */
 /* arithmetic core of dvae_gemm_f32 and of every product the entry points below launch through it:
  * 0 = v_mfma_f32_32x32x2_f32; 1 = each fp32 operand split exactly into three bf16 pieces while it is staged,
  * the product formed from the six piece products above 2^-24 |a b| on v_mfma_f32_32x32x16_bf16 with fp32
