@@ -664,6 +664,12 @@ int launch(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
   return DVAE_OK;
 }
 
+template <int AKM, int BKM, int BM, int BN, int WM, int WN>
+int launch_pf(int pf, const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) {
+  if (pf == 1) return launch<AKM, BKM, BM, BN, WM, WN, 32, 1, 2, false, true, 1>(d, ws, ws_bytes, stream);
+  return launch<AKM, BKM, BM, BN, WM, WN, 32, 1, 2, false, true, 2>(d, ws, ws_bytes, stream);
+}
+
 }  // namespace
 
 extern "C" int dvae_gemm_tune(int splitk_blocks, int force_prio) {
@@ -760,10 +766,11 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
     if (flat) return launch<AK, BKK, 32, 128, 1, 4, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);     \
     /* prefetch form (pf_of): 1 = the next tile's split held behind this tile's products, 2 = two k-tiles in flight */ \
     const int pf = pf_of(AK, BKK, quarter);                                                  \
+    if (g_force_tile == 4) return launch_pf<AK, BKK, 128, 64, 2, 2>(pf ? pf : 2, d, ws, ws_bytes, stream);   /* lab */ \
     if (pf) {                                                                                \
-      if (quarter) return pf == 1 ? launch<AK, BKK, 64, 64, 2, 2, 32, 1, 2, false, true, 1>(d, ws, ws_bytes, stream) : launch<AK, BKK, 64, 64, 2, 2, 32, 1, 2, false, true, 2>(d, ws, ws_bytes, stream);   \
-      if (half) return pf == 1 ? launch<AK, BKK, 64, 128, 1, 4, 32, 1, 2, false, true, 1>(d, ws, ws_bytes, stream) : launch<AK, BKK, 64, 128, 1, 4, 32, 1, 2, false, true, 2>(d, ws, ws_bytes, stream);   \
-      return pf == 1 ? launch<AK, BKK, 128, 128, 2, 2, 32, 1, 2, false, true, 1>(d, ws, ws_bytes, stream) : launch<AK, BKK, 128, 128, 2, 2, 32, 1, 2, false, true, 2>(d, ws, ws_bytes, stream);   \
+      if (quarter) return launch_pf<AK, BKK, 64, 64, 2, 2>(pf, d, ws, ws_bytes, stream);     \
+      if (half) return launch_pf<AK, BKK, 64, 128, 1, 4>(pf, d, ws, ws_bytes, stream);       \
+      return launch_pf<AK, BKK, 128, 128, 2, 2>(pf, d, ws, ws_bytes, stream);                \
     }                                                                                        \
     if (quarter) return launch<AK, BKK, 64, 64, 2, 2, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);   \
     return half ? launch<AK, BKK, 64, 128, 1, 4, 32, 1, 2, false, true>(d, ws, ws_bytes, stream)         \

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256, 2) void level_kernel(LevelCore p, Epi e) {
 // The same fused level step on the x6 arithmetic core (x6.h: operands split exactly into three bf16 pieces while staged,
 // six v_mfma_f32_32x32x16_bf16 per fp32 product): k-tile 32, both operands m-major, the weight tile's LDS row is
 // gate * 64 + hidden unit as above, so the epilogues are shared.
-template <int G, int TM, class Epi>
+// PF: prefetch form of the main loop as in gemm.hip (1 = the next tile's split held behind this tile's products,
+// 2 = two k-tiles in flight).
+template <int G, int TM, class Epi, int PF = 0>
 __global__ __launch_bounds__(256, 2) void level_x6_kernel(LevelCore p, Epi e) {
   constexpr int BM = 64 * TM;
   using TA = XTile<0, BM>;
@@ -359,14 +361,40 @@ __global__ __launch_bounds__(256, 2) void level_x6_kernel(LevelCore p, Epi e) {
   ta.store(As, tid);
   tb.store(Bs, tid);
   __syncthreads();
-  for (int k0 = 0; k0 + 32 < p.K; k0 += 32) {
+  auto refill_from = [&](const TA& a, const TB& b) {
+    __syncthreads();
+    a.store(As, tid);
+    b.store(Bs, tid);
+    __syncthreads();
+  };
+  int k0 = 0;
+  if constexpr (PF == 2) {
+    if (k0 + 64 <= p.K) {
+      TA ta2 = ta;
+      TB tb2 = tb;
+      ta.template load<false>(p.A, p.lda, m0, p.M, k0 + 32, p.K, tid);
+      tb.template load<false>(p.W, p.ldw, 0, 0, k0 + 32, p.K, tid);
+      for (; k0 + 128 <= p.K; k0 += 64) {
+        ta2.template load<false>(p.A, p.lda, m0, p.M, k0 + 64, p.K, tid);
+        tb2.template load<false>(p.W, p.ldw, 0, 0, k0 + 64, p.K, tid);
+        compute();
+        refill_from(ta, tb);
+        ta.template load<false>(p.A, p.lda, m0, p.M, k0 + 96, p.K, tid);
+        tb.template load<false>(p.W, p.ldw, 0, 0, k0 + 96, p.K, tid);
+        compute();
+        refill_from(ta2, tb2);
+      }
+      compute();
+      refill_from(ta, tb);
+      k0 += 32;
+    }
+  }
+  for (; k0 + 32 < p.K; k0 += 32) {
     ta.template load<false>(p.A, p.lda, m0, p.M, k0 + 32, p.K, tid);
     tb.template load<false>(p.W, p.ldw, 0, 0, k0 + 32, p.K, tid);
     compute();
-    __syncthreads();
-    ta.store(As, tid);
-    tb.store(Bs, tid);
-    __syncthreads();
+    if constexpr (PF == 1) __builtin_amdgcn_sched_barrier(0);
+    refill_from(ta, tb);
   }
   compute();
 
@@ -632,10 +660,20 @@ int launch_level(LevelCore c, const Epi& e, hipStream_t st) {
   void* pr = gemm_prof_begin(2.0 * c.M * G * c.HP * (double)c.K, st);
   c.nblk = cdiv(c.M, big ? 128 : 64) * c.tiles_n;
   if constexpr (!GATHER) {
+    // prefetch form (as gemm.hip's pf_of): two k-tiles in flight by default -- same box headline -0.4 %, c3 -1.1 %, c2 neutral
+    static const int pf = getenv("DVAE_LEVEL_PF") ? atoi(getenv("DVAE_LEVEL_PF")) : 2;   // A-B knob
     if constexpr (G != 3) {
-      if (x6 && big) hipLaunchKernelGGL((level_x6_kernel<G, 2, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+      if (x6 && big) {
+        if (pf == 1) hipLaunchKernelGGL((level_x6_kernel<G, 2, Epi, 1>), dim3(c.nblk), dim3(256), 0, st, c, e);
+        else if (pf == 2) hipLaunchKernelGGL((level_x6_kernel<G, 2, Epi, 2>), dim3(c.nblk), dim3(256), 0, st, c, e);
+        else hipLaunchKernelGGL((level_x6_kernel<G, 2, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+      }
     }
-    if (x6 && !big) hipLaunchKernelGGL((level_x6_kernel<G, 1, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+    if (x6 && !big) {
+      if (pf == 1) hipLaunchKernelGGL((level_x6_kernel<G, 1, Epi, 1>), dim3(c.nblk), dim3(256), 0, st, c, e);
+      else if (pf == 2) hipLaunchKernelGGL((level_x6_kernel<G, 1, Epi, 2>), dim3(c.nblk), dim3(256), 0, st, c, e);
+      else hipLaunchKernelGGL((level_x6_kernel<G, 1, Epi>), dim3(c.nblk), dim3(256), 0, st, c, e);
+    }
   }
   if (!x6 && big) hipLaunchKernelGGL((level_kernel<G, 2, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);
   if (!x6 && !big) hipLaunchKernelGGL((level_kernel<G, 1, Epi, GATHER>), dim3(c.nblk), dim3(256), 0, st, c, e);

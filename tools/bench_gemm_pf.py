@@ -21,7 +21,8 @@ def timed(fn, n=20):
 shapes = [("nt", 57344, 1536, 512), ("nt", 32768, 512, 512), ("nt", 4096, 1536, 512), ("nt", 4096, 1024, 512), ("nt", 28672, 2048, 512),
           ("nn", 4096, 512, 1536), ("nn", 4096, 512, 1024), ("nn", 57344, 512, 1536), ("nn", 28672, 512, 2048), ("nn", 90000, 512, 2048),
           ("tn", 1536, 512, 57344), ("tn", 2048, 512, 28672), ("tn", 1024, 512, 28672),
-          ("nt", 2048, 1536, 512), ("nn", 2048, 512, 1536)]
+          ("nt", 2048, 1536, 512), ("nn", 2048, 512, 1536), ("tn", 1536, 512, 4096), ("tn", 1024, 512, 4096), ("tn", 1536, 512, 2048)]
+if len(sys.argv) > 2: shapes = shapes[-int(sys.argv[2]):]
 for form, M, N, K in shapes:
     if form == "nt": A, W, akm, bkm = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), 0, 0
     elif form == "nn": A, W, akm, bkm = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev), 0, 1
@@ -32,12 +33,12 @@ for form, M, N, K in shapes:
     out, ref = [], None
     for rep in range(2):
         for v in VARS:
-            lib.dvae_gemm_pf(v)
+            lib.dvae_gemm_pf(v % 10); lib.dvae_gemm_force_tile(v // 10)
             t = timed(call)
             if rep == 0:
                 if ref is None: ref = C.clone()
                 assert torch.equal(C, ref), "variant %d differs" % v
             out.append((v, t))
-    lib.dvae_gemm_pf(-1)
+    lib.dvae_gemm_pf(-1); lib.dvae_gemm_force_tile(0)
     fl = 2.0 * M * N * K
     print('%s M=%6d N=%5d K=%6d  ' % (form, M, N, K) + '  '.join('v%d %7.1f us %5.1f TF' % (v, t, fl / t / 1e6) for v, t in out), flush=True)
