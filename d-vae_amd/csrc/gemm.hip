@@ -766,7 +766,6 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
     if (flat) return launch<AK, BKK, 32, 128, 1, 4, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);     \
     /* prefetch form (pf_of): 1 = the next tile's split held behind this tile's products, 2 = two k-tiles in flight */ \
     const int pf = pf_of(AK, BKK, quarter);                                                  \
-    if (g_force_tile == 4) return launch_pf<AK, BKK, 128, 64, 2, 2>(pf ? pf : 2, d, ws, ws_bytes, stream);   /* lab */ \
     if (pf) {                                                                                \
       if (quarter) return launch_pf<AK, BKK, 64, 64, 2, 2>(pf, d, ws, ws_bytes, stream);     \
       if (half) return launch_pf<AK, BKK, 64, 128, 1, 4>(pf, d, ws, ws_bytes, stream);       \
