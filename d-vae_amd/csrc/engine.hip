@@ -1069,7 +1069,11 @@ extern "C" int dvae_decoder_bwd(const dvae_dims* dp, const float* z, const float
       DVAE_TRY(g.nn(w.DA + (size_t)n0 * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)n0 * HP, HP, n1 - n0, HP, EHP));
     // edge rows: the scored ones, zeros in the others
     if (U >= 0) {
-      DVAE_TRY(k_zero_rows(w.s.DH, HP, HP, sv.a_skip, lv.E - U, st));
+      // the unscored rows are not written at all: the GRU backward takes their dL/dHV as zero (SweepBufs::apos);
+      // DVAE_ZERO_SKIPPED=1 zero-fills them as before (A-B tests)
+      static const bool zero_skipped = getenv("DVAE_ZERO_SKIPPED") != nullptr;
+      if (zero_skipped) DVAE_TRY(k_zero_rows(w.s.DH, HP, HP, sv.a_skip, lv.E - U, st));
+      else w.s.apos = sv.a_pos;
       DVAE_TRY(g.nn(w.DA, EHP, P + L.W1a, HP, w.s.DH, HP, U, HP, EHP, 0, sv.a_rows));
     } else {
       DVAE_TRY(g.nn(w.DA + (size_t)R * EHP, EHP, P + L.W1a, HP, w.s.DH + (size_t)R * HP, HP, RH - R, HP, EHP));

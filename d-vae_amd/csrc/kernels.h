@@ -44,6 +44,10 @@ struct SweepBufs {
   // node, PG[u] = Whh.GM[u], instead of being computed per prefix row (E + N rows -> N rows)
   float* PG;        // [R][3HP]  Whh.GM[u] -> after the backward gather: dL/dPG[u] = sum of dgh over the rows that hold u
   float* DGM;       // [R][HP]   backward: dL/dGM[u] (direct part gathered, hidden part added by a GEMM)
+  // prefix sweeps, backward: when set (SchedView::a_pos), only the SCORED edge rows of DH were written on entry -- edge row e
+  // is scored iff apos[e + 1] != apos[e] -- and the GRU backward takes dL/dHV of the others as zero instead of reading it
+  // (they used to be zero-filled, kernels.hip zero_rows_kernel)
+  const int* apos = nullptr;
 };
 
 // with_pg (prefix sweeps): also sums the nodes' hidden products PG into the GH rows of the prefix rows

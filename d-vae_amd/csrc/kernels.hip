@@ -230,7 +230,8 @@ __global__ void prefix_gru_fwd_kernel(SchedDir S, int R, int ns, int ne, const f
 __global__ void prefix_gru_bwd_kernel(SchedDir S, int R, int ns, int ne, const float* __restrict__ GM,
                                       const float* __restrict__ PG, float* __restrict__ GH, float* __restrict__ GHN,
                                       float* __restrict__ DH, const float* __restrict__ DHn, const float* __restrict__ x,
-                                      int N, int C, GruW w, int HP, GemmPartials parts, int parts_row0) {
+                                      int N, int C, GruW w, int HP, GemmPartials parts, int parts_row0,
+                                      const int* __restrict__ apos) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(ne - ns) * HP4;
   ITEM_LOOP(total) {
@@ -259,7 +260,8 @@ __global__ void prefix_gru_bwd_kernel(SchedDir S, int R, int ns, int ne, const f
       g2 = add4(g2, ld4(pu + 2 * HP));
       const float4 ghr = add4(br, g0), ghz = add4(bz, g1), ghn = add4(bn, g2);
       const size_t row = (size_t)R + p + t;
-      float4 dh = ld4(DH + row * HP + j);
+      // an unscored row (only a node's full prefix can be one) has no gradient of its own: nothing was written there
+      float4 dh = (!apos || t < deg - 1 || apos[p + t + 1] != apos[p + t]) ? ld4(DH + row * HP + j) : zero4();
       if (t == deg - 1) {   // the node's final state also takes the gradient of everything that reads the node (gru_bwd_kernel)
         float4 e = ld4(DHn + (size_t)r * HP + j);
         if (parts.slab) {
@@ -532,12 +534,13 @@ __global__ void gm_bwd_apply_kernel(int ns, int ne, const float* __restrict__ DG
 __global__ void gru_bwd_kernel(SchedDir S, int R, int p0, int p1, int prefix, float* __restrict__ GH,
                                float* __restrict__ GHN, const float* __restrict__ AGG,
                                float* __restrict__ DH, const float* __restrict__ DHn, int HP,
-                               GemmPartials parts, int parts_row0) {
+                               GemmPartials parts, int parts_row0, const int* __restrict__ apos) {
   const int HP4 = HP >> 2;
   const long long total = (long long)(p1 - p0) * HP4;
   ITEM_LOOP(total) {
     const int p = p0 + (int)(it / HP4), j = (int)(it % HP4) * 4;
-    float4 dh = ld4(DH + (size_t)p * HP + j);
+    // apos (prefix sweeps): an unscored edge row has no gradient of its own, nothing was written there
+    float4 dh = (!apos || p < R || apos[p - R + 1] != apos[p - R]) ? ld4(DH + (size_t)p * HP + j) : zero4();
     // parts: the gate/map input gradient of node rows [parts_row0, ..) still as split-K slabs; it belongs to
     // the table the product accumulates into (DH of the node row, or DHn for prefix sweeps) and is added
     // first, as the combine launch would have
@@ -1842,7 +1845,7 @@ int k_prefix_gru_bwd(const SchedDir& S, int ns, int ne, const SweepBufs& b, cons
                      hipStream_t st, const GemmPartials* parts, int parts_row0) {
   if (ne <= ns) return DVAE_OK;
   hipLaunchKernelGGL(prefix_gru_bwd_kernel, grid_for((long long)(ne - ns) * (HP / 4)), dim3(256), 0, st, S, b.R, ns, ne, b.GM,
-                     b.PG, b.GH, b.GHN, b.DH, b.DHn, x, N, C, w, HP, parts ? *parts : GemmPartials{nullptr, 1, 0}, parts_row0);
+                     b.PG, b.GH, b.GHN, b.DH, b.DHn, x, N, C, w, HP, parts ? *parts : GemmPartials{nullptr, 1, 0}, parts_row0, b.apos);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
@@ -1929,7 +1932,7 @@ int k_gru_bwd(const SchedDir& S, int p0, int p1, const SweepBufs& b, int HP, hip
   if (p1 <= p0) return DVAE_OK;
   hipLaunchKernelGGL(gru_bwd_kernel, grid_for((long long)(p1 - p0) * (HP / 4)), dim3(256), 0, st, S, b.R, p0, p1,
                      b.prefix, b.GH, b.GHN, b.AGG, b.DH, b.DHn, HP, parts ? *parts : GemmPartials{nullptr, 1, 0},
-                     parts_row0);
+                     parts_row0, b.prefix ? b.apos : nullptr);
   DVAE_LAUNCH_CHECK();
   return DVAE_OK;
 }
