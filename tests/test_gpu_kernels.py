@@ -139,6 +139,40 @@ def test_gemm_tn(cuda, M, N, K, core):
 
 
 @pytest.mark.parametrize("form", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N", [(4096, 512), (300, 1536), (4096, 2048)])
+def test_gemm_prefetch_forms_bit_identical(cuda, form, M, N):
+    """The x6 main loop's prefetch forms (gemm.hip pf_of: 0 plain, 1 split held behind the products, 2 two k-tiles in
+    flight) change the schedule, not the arithmetic: every form gives the same bits as the plain loop, on reductions of
+    one to many k-tiles, ragged ones included (the two-deep form's prologue, unrolled pairs and drain), on 64x64, 64x128
+    and 128x128 tiles, and the product is right against fp64."""
+    from dvae_amd._lib import load
+    lib = load()
+    lib.dvae_gemm_x6(1)
+    torch.manual_seed(5)
+    try:
+        for K in (32, 36, 64, 96, 100, 128, 160, 192, 224, 260, 512, 1028):
+            if form == "nt":
+                A, W, akm, bkm = torch.randn(M, K, device=cuda), torch.randn(N, K, device=cuda), 0, 0
+                ref = A.double() @ W.double().t()
+            elif form == "nn":
+                A, W, akm, bkm = torch.randn(M, K, device=cuda), torch.randn(K, N, device=cuda), 0, 1
+                ref = A.double() @ W.double()
+            else:
+                A, W, akm, bkm = torch.randn(K, M, device=cuda), torch.randn(K, N, device=cuda), 1, 1
+                ref = A.double().t() @ W.double()
+            outs = []
+            for pf in (0, 1, 2, -1):
+                lib.dvae_gemm_pf(pf)
+                outs.append(_gemm(lib, A, akm, W, bkm, M, N, K))
+            assert torch.allclose(outs[0].double(), ref, rtol=1e-5, atol=1e-4 * K ** 0.5), (form, K)
+            for pf, o in zip((1, 2, -1), outs[1:]):
+                assert torch.equal(o, outs[0]), (form, K, pf)
+    finally:
+        lib.dvae_gemm_pf(-1)
+        lib.dvae_gemm_x6(int(__import__("os").environ.get("DVAE_GEMM_X6", "1")))
+
+
+@pytest.mark.parametrize("form", ["nt", "nn", "tn"])
 def test_gemm_x6_is_fp32_accurate(cuda, form):
     """The split-operand core drops only piece products below 2^-24 |a b|: against an fp64 product its error is that
     of the fp32 MFMA core (same fp32 accumulation), nowhere near bf16's 2^-8."""
