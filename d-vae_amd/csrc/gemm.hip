@@ -346,7 +346,8 @@ __global__ __launch_bounds__(512, 1) void gemm_wsk_kernel(GemmParams p) {
 
 template <int AKM, int BKM, int BM, int BN, int WM, int WN, int BK, int ST, int MINB = 2, bool KG = false, bool X6 = false, int PF = 0>
 __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
-  static_assert(PF == 0 || (!KG && ST == 1), "deeper prefetch: plain operands, one LDS stage");
+  static_assert(PF == 0 || ST == 1, "prefetch forms: one LDS stage");
+  static_assert(PF != 2 || !KG, "two k-tiles in flight: plain operands only");
   static_assert(!KG || (AKM == 1 && BKM == 1), "a gathered reduction needs two k-major operands");
   static_assert(!X6 || BK == 32, "the x6 core stages 32-wide k-tiles");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -496,6 +497,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
       tb.load_gathered(p.B, p.ldb, n0, p.N, tid);
       ta.kq_fetch(p.k_map, k0 + 2 * BK, ke, tid);   // rows of the tile after this one
       tb.kq_fetch(p.k_map, k0 + 2 * BK, ke, tid);
+      // gathered rows, form 1: left alone the compiler sinks these loads (they wait for the row indices) to the middle of
+      // the tile's products and then waits for them almost at once; the barrier keeps them at the top of the iteration
+      if constexpr (PF == 1) __builtin_amdgcn_sched_barrier(0);
     } else if (!(p.dbg & 2)) {
       ta.template load<false>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
       tb.template load<false>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
@@ -721,7 +725,11 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
     // gathered reduction rows: the weight-gradient shape only (TN, 128x128 tiles, split K)
     DVAE_REQUIRE(d.a_kmajor && d.b_kmajor && (d.M & 3) == 0 && (d.N & 3) == 0 && d.N > 32,
                  "gemm: a reduction map needs two k-major operands and N > 32");
-    if (g_x6) return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true>(d, ws, ws_bytes, stream);
+    if (g_x6) {
+      // (form 1 of the main loop: loads at the top of the iteration, split behind the products; DVAE_GEMM_PF=0: A-B tests)
+      if (g_pf != 0) return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true, 1>(d, ws, ws_bytes, stream);
+      return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true>(d, ws, ws_bytes, stream);
+    }
     return launch<1, 1, 128, 128, 2, 2, 16, 1, 2, true>(d, ws, ws_bytes, stream);
   }
   DVAE_REQUIRE(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0, "gemm: operands must be 16-byte aligned");
