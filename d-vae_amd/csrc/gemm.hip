@@ -497,9 +497,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_f32_kernel(GemmParams p) {
       tb.load_gathered(p.B, p.ldb, n0, p.N, tid);
       ta.kq_fetch(p.k_map, k0 + 2 * BK, ke, tid);   // rows of the tile after this one
       tb.kq_fetch(p.k_map, k0 + 2 * BK, ke, tid);
-      // gathered rows, form 1: left alone the compiler sinks these loads (they wait for the row indices) to the middle of
-      // the tile's products and then waits for them almost at once; the barrier keeps them at the top of the iteration
-      if constexpr (PF == 1) __builtin_amdgcn_sched_barrier(0);
+      // gathered rows, forms 1 and 3: left alone the compiler sinks these loads (they wait for the row indices) to the middle
+      // of the tile's products and then waits for them almost at once; the barrier keeps them at the top of the iteration
+      if constexpr (PF == 1 || PF == 3) __builtin_amdgcn_sched_barrier(0);
     } else if (!(p.dbg & 2)) {
       ta.template load<false>(p.A, p.lda, m0, p.M, k0 + BK, ke, tid);
       tb.template load<false>(p.B, p.ldb, n0, p.N, k0 + BK, ke, tid);
@@ -726,8 +726,11 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
     DVAE_REQUIRE(d.a_kmajor && d.b_kmajor && (d.M & 3) == 0 && (d.N & 3) == 0 && d.N > 32,
                  "gemm: a reduction map needs two k-major operands and N > 32");
     if (g_x6) {
-      // (form 1 of the main loop: loads at the top of the iteration, split behind the products; DVAE_GEMM_PF=0: A-B tests)
-      if (g_pf != 0) return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true, 1>(d, ws, ws_bytes, stream);
+      // gathered rows: the loads held at the top of the iteration (form 3; form 1 also keeps the split behind the products:
+      // 4 % slower here, the k-major staging likes its split woven into the MFMA stream).  tools/bench_gemm_kmap.py, 80 % of
+      // 57344 rows kept: plain loop 720 us, form 1 632, form 3 606 (plain TN of the same K: 520).  DVAE_GEMM_PF=0 | 1: A-B tests
+      if (g_pf == 1) return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true, 1>(d, ws, ws_bytes, stream);
+      if (g_pf != 0) return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true, 3>(d, ws, ws_bytes, stream);
       return launch<1, 1, 128, 128, 2, 2, 32, 1, 2, true, true>(d, ws, ws_bytes, stream);
     }
     return launch<1, 1, 128, 128, 2, 2, 16, 1, 2, true>(d, ws, ws_bytes, stream);

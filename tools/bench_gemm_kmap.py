@@ -27,8 +27,10 @@ for keep in (1.0, 0.8, 0.5):
     for rep in range(2):
         tp = timed(plain)
         lib.dvae_gemm_pf(0); tm0 = timed(mapped); c0 = C.clone()
+        lib.dvae_gemm_pf(1); tm1 = timed(mapped)
         lib.dvae_gemm_pf(-1); tm = timed(mapped)
         assert torch.equal(C, c0)
+    print('   form 1 (also the split behind the products): %7.1f us' % tm1)
     fl = 2.0 * M * N * K
-    print('K=%6d of %d rows: plain %7.1f us %5.1f TF   gathered, plain loop %7.1f us %5.1f TF   gathered, form 1 %7.1f us %5.1f TF' % (
+    print('K=%6d of %d rows: plain %7.1f us %5.1f TF   gathered, plain loop %7.1f us %5.1f TF   gathered, loads at the top (default) %7.1f us %5.1f TF' % (
         K, rows, tp, fl / tp / 1e6, tm0, fl / tm0 / 1e6, tm, fl / tm / 1e6), flush=True)
