@@ -686,7 +686,7 @@ static int g_x6 = getenv("DVAE_GEMM_X6") ? atoi(getenv("DVAE_GEMM_X6")) : 1;
 extern "C" int dvae_gemm_x6(int on) { g_x6 = on; return DVAE_OK; }
 extern "C" int dvae_gemm_core(void) { return g_x6; }
 int gemm_x6_enabled() { return g_x6; }
-static int g_force_tile = 0;   // tuning knob (tests/bench_gemm.py): 0 auto, 1 128x128, 2 64x128, 3 64x64
+static int g_force_tile = 0;   // tuning knob (tests/bench_gemm.py): 0 auto, 1 128x128, 2 64x128, 3 64x64, 4 128x96 (x6 NT, N % 96 == 0)
 extern "C" int dvae_gemm_force_tile(int mode) { g_force_tile = mode; return DVAE_OK; }
 
 namespace {
@@ -770,6 +770,17 @@ int gemm_f32(const GemmDesc& d, float* ws, size_t ws_bytes, hipStream_t stream) 
       d.K >= 512 && (d.N & 3) == 0) {
     const long long t = (long long)cdiv(d.M, 128) * cdiv(d.N, 64);
     if (t >= 224 && t <= 512) return launch_wsk(d, stream);
+  }
+  // 128 x 96 tiles (x6 core, NT products): an output of ~4096 x 1536 is 768 tiles of 64 x 128 -- one and a half rounds of the
+  // 512 workgroup slots -- or 384 of 128 x 128; 128 x 96 makes it exactly 512 (one round, two workgroups on every CU)
+  static const bool t96_off = getenv("DVAE_NO_TILE96") != nullptr;   // A-B tests
+  if (g_x6 && !d.a_kmajor && !d.b_kmajor && !narrow && !flat && d.N % 96 == 0 && (g_force_tile == 4 || (g_force_tile == 0 && !t96_off && half))) {
+    const long long t96 = (long long)cdiv(d.M, 128) * (d.N / 96);
+    if (g_force_tile == 4 || (t96 > 384 && t96 <= 512)) {
+      const int pf = pf_of(0, 0, false);
+      if (pf) return launch_pf<0, 0, 128, 96, 4, 1>(pf, d, ws, ws_bytes, stream);
+      return launch<0, 0, 128, 96, 4, 1, 32, 1, 2, false, true>(d, ws, ws_bytes, stream);
+    }
   }
 #define GEMM_PICK(AK, BKK)                                                                   \
   if (g_x6) {                                                                                \
