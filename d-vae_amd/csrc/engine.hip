@@ -39,7 +39,9 @@ struct LevelCfg {
   int node_hidden = getenv("DVAE_NO_NODE_HIDDEN") ? 0 : 1;   // prefix sweeps: one hidden product per node (SweepBufs::PG)
   // per-level products of at most this many rows run as level.hip small_kernel launches (32-row tiles, K split
   // over the waves of a workgroup, gates fused in the forward pass); 0 = never.  DVAE_SMALL_ROWS / dvae_small_rows_tune
-  int small_rows = getenv("DVAE_SMALL_ROWS") ? atoi(getenv("DVAE_SMALL_ROWS")) : 1024;
+  // (768 since the x6 GEMM's 64x64 tiles run with two k-tiles in flight: 1024-row levels now take the GEMM path, B = 1024 3.128 ->
+  // 3.084 ms same box; 512-row levels keep the small kernels, B = 512 2.05 vs 2.16 without them)
+  int small_rows = getenv("DVAE_SMALL_ROWS") ? atoi(getenv("DVAE_SMALL_ROWS")) : 768;
   LevelCfg() {
     type_share = getenv("DVAE_NO_TYPE_SHARE") ? 0 : 1;
     // -2 = automatic: from 2048 rows up (the fused kernel runs on the arithmetic core the GEMM uses, level.hip)

@@ -294,7 +294,7 @@ int dvae_step_part2(const dvae_step* s, void* stream, void* side_stream);
  * combination computes the same formulas (fp32 summation order may differ). */
 int dvae_level_tune(int fused_gm_min_rows, int fused_gru, int type_share);
 /* tuning / test knob: per-level products of at most `rows` rows run on the small-level kernels (32-row tiles, the
- * reduction split over the waves of a workgroup, gates fused into the forward products; default 1024, environment
+ * reduction split over the waves of a workgroup, gates fused into the forward products; default 768, environment
  * DVAE_SMALL_ROWS); 0 = never.  Same formulas either way (fp32 summation order differs). */
 int dvae_small_rows_tune(int rows);
 /* tuning / test knob: decoder sweep levels (mod None) of at least min_rows node rows do not save the GRU gates of their prefix

@@ -70,7 +70,7 @@ def test_small_level_kernels(cuda, mod, bidir, B):
         with torch.no_grad():
             ref_states = model.encoder.node_states(X)[0].clone()
             ref_logits = [t.clone() for t in model.decoder(eps, X)]
-        for rows in (1 << 30, 1024):
+        for rows in (1 << 30, 1024, 768):
             lib.dvae_small_rows_tune(rows)
             out = _step(model, X, eps)
             with torch.no_grad():
@@ -83,7 +83,7 @@ def test_small_level_kernels(cuda, mod, bidir, B):
             rel = float((out[1] - ref[1]).norm() / ref[1].norm())      # ReLU kinks: see test_fused_level_kernels
             assert rel <= 1e-3, "gradients, small rows %d: relative L2 error %.3e" % (rows, rel)
     finally:
-        lib.dvae_small_rows_tune(1024)
+        lib.dvae_small_rows_tune(768)     # the library's default
 
 
 def test_prepared_schedule_bitwise(cuda):
