@@ -41,14 +41,14 @@ static int g_variant = 0;           // lab knob (fp32-MFMA core): 0 default (k-t
 // x6 core, prefetch form of the 64x64 / 64x128 / 128x128 kernels: -1 by shape (pf_of below), 0 / 1 / 2 forced (A-B tests)
 static int g_pf = getenv("DVAE_GEMM_PF") ? atoi(getenv("DVAE_GEMM_PF")) : -1;
 extern "C" int dvae_gemm_variant(int v) { g_variant = v; return 0; }
-extern "C" int dvae_gemm_pf(int v) { g_pf = v; return 0; }
+extern "C" int dvae_gemm_pf(int v) { g_pf = (v >= 0 && v <= 2) ? v : -1; return 0; }
 // tools/bench_gemm_pf.py, same box: the compiler weaves the next tile's split arithmetic into this tile's MFMA stream and
 // waits for the loads it has only just issued after the FIRST product.  Holding the split behind the products
 // (sched_barrier) gains 1.5-3 % on the large NT / NN shapes; two k-tiles in flight gain 11-16 % on the 4096-row NN products
 // (64x64 tiles, latency-bound: 119 -> 132 TF at K = 1536) and 5 % on the NT ones; the weight-gradient (TN) shapes lose 3-5 %
 // with either and keep the plain form.
 static inline int pf_of(int a_kmajor, int b_kmajor, bool quarter) {
-  if (g_pf >= 0) return g_pf;
+  if (g_pf >= 0 && g_pf <= 2) return g_pf;
   if (a_kmajor) return 0;
   (void)b_kmajor;
   return quarter ? 2 : 1;

@@ -37,7 +37,8 @@ for form, M, N, K in shapes:
             t = timed(call)
             if rep == 0:
                 if ref is None: ref = C.clone()
-                assert torch.equal(C, ref), "variant %d differs" % v
+                if v < 10: assert torch.equal(C, ref), "variant %d differs" % v      # (a forced tile may change the split-K factor)
+                else: assert torch.allclose(C, ref, rtol=1e-4, atol=1e-3 * K ** 0.5), "variant %d is wrong" % v
             out.append((v, t))
     lib.dvae_gemm_pf(-1); lib.dvae_gemm_force_tile(0)
     fl = 2.0 * M * N * K
