@@ -16,6 +16,8 @@ batches = []
 for i in range(4):
     g, x = dvae_amd.synth.enas_like(4096, 100 + i)
     batches.append({'graph': g.to(dev), 'node_encoding': x.to(dev)})
+if len(sys.argv) > 3:                                          # learning rate override (0: the weights never move)
+    for gq in opt.param_groups: gq['lr'] = float(sys.argv[3])
 prepared = {}
 def step(i):
     sched = prepared.pop(i, None)
