@@ -34,6 +34,12 @@ if SPIN > 0:
     while time.time() - t0 < SPIN:
         for _ in range(10): a @ a
         torch.cuda.synchronize()
+elif SPIN < 0:                                                  # -n: n steps on the fp32-MFMA core in front (bench.py's comparison leg)
+    from dvae_amd import _lib
+    lib = _lib.load(); lib.dvae_gemm_x6(0)
+    import time; time.sleep(1.0)
+    for i in range(int(-SPIN)): step(2000 + i)
+    torch.cuda.synchronize(); lib.dvae_gemm_x6(1); prepared.clear()
 else:
     import time; time.sleep(1.0)                                # an idle second, as between set-up and the timed loop
 for i in range(N):
