@@ -21,7 +21,8 @@ def timed(fn, n=20):
 shapes = [("nt", 57344, 1536, 512), ("nt", 32768, 512, 512), ("nt", 4096, 1536, 512), ("nt", 4096, 1024, 512), ("nt", 28672, 2048, 512),
           ("nn", 4096, 512, 1536), ("nn", 4096, 512, 1024), ("nn", 57344, 512, 1536), ("nn", 28672, 512, 2048), ("nn", 90000, 512, 2048),
           ("tn", 1536, 512, 57344), ("tn", 2048, 512, 28672), ("tn", 1024, 512, 28672),
-          ("nt", 2048, 1536, 512), ("nn", 2048, 512, 1536), ("tn", 1536, 512, 4096), ("tn", 1024, 512, 4096), ("tn", 1536, 512, 2048)]
+          ("nt", 2048, 1536, 512), ("nn", 2048, 512, 1536), ("tn", 1536, 512, 4096), ("tn", 1024, 512, 4096), ("tn", 1536, 512, 2048),
+          ("nt", 4096, 512, 1536), ("nn", 4096, 512, 1536), ("nt", 4096, 512, 1024), ("nn", 4096, 512, 1024)]
 if len(sys.argv) > 2: shapes = shapes[-int(sys.argv[2]):]
 for form, M, N, K in shapes:
     if form == "nt": A, W, akm, bkm = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), 0, 0
