@@ -33,7 +33,8 @@ def _gemm(lib, A, a_km, Bm, b_km, M, N, K, bias=None, relu=0, acc=None, ws_mb=64
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (4096, 1536, 512), (1000, 1024, 512), (37, 32, 1024),
                                    (300, 2048, 64), (5, 128, 2048), (64, 512, 1024), (100, 512, 2048),
-                                   (64, 128, 1024), (48, 1536, 512)])
+                                   (64, 128, 1024), (48, 1536, 512),
+                                   (3900, 1536, 512), (4096, 1440, 256)])   # the 128x96 tiles (x6 core), ragged rows / 15 column tiles
 def test_gemm_nt(cuda, M, N, K, core):
     from dvae_amd._lib import load
     lib = load()
